@@ -1,0 +1,273 @@
+/*
+ * rpt_gpu.h — C ABI of the MI355X (gfx950) path-tracing back-end for the `rpt` renderer.
+ *
+ * This is the drop-in boundary for rpt's one hot path: the body of
+ * `Renderer::sample(&self, iterations, &mut Buffer)` (reference src/renderer.rs:117-129),
+ * which both public entry points call (`render` renderer.rs:96-100, `iterative_render`
+ * renderer.rs:103-115).  The reference has no FFI of its own (`#![forbid(unsafe_code)]`,
+ * src/lib.rs:3); the entry points below are what an `rpt-gpu-sys` style binding would bind
+ * (see INTEGRATION.md for the Rust / ctypes / C++ stubs).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no C++/torch types;
+ *   - every POD struct mirrors a reference struct field by field (cited per struct);
+ *   - matrices are column-major, exactly as nalgebra/glm stores them
+ *     (element (row r, col c) of a 4x4 is m[c*4+r], of a 3x3 is m[c*3+r]);
+ *   - every function returns 0 (RPTGPU_OK) or a negative RPTGPU_E_* code, never throws,
+ *     never aborts; rptgpu_strerror() / rptgpu_last_error_detail() explain;
+ *   - the caller owns every input pointer and every output buffer for the duration of the
+ *     call only; the library copies what it needs to device memory in rptgpu_scene_create;
+ *   - a handle is NOT re-entrant (one render in flight per handle); distinct handles may be
+ *     used from distinct threads.  All calls are synchronous unless they take a stream.
+ */
+#ifndef RPT_GPU_H
+#define RPT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPTGPU_ABI_VERSION 1
+
+/* ---- error codes (replace the reference's panics: buffer.rs:26,33,89, plane.rs:35) ---- */
+enum {
+  RPTGPU_OK = 0,
+  RPTGPU_E_INVALID_ARGUMENT = -1,
+  RPTGPU_E_UNSUPPORTED_SHAPE = -2, /* shape outside the closed device set          */
+  RPTGPU_E_NO_DEVICE = -3,         /* no HIP device / HIP runtime failure at init              */
+  RPTGPU_E_HIP = -4,               /* a HIP call failed; see rptgpu_last_error_detail          */
+  RPTGPU_E_OUT_OF_MEMORY = -5,
+  RPTGPU_E_TREE_TOO_DEEP = -6,     /* kd-tree deeper than the device traversal stack           */
+  RPTGPU_E_UNIMPLEMENTED_SAMPLE = -7 /* Light::Object over a Plane: plane.rs:34-36 panics      */
+};
+
+/* ---- Material: src/material.rs:8-26 ---- */
+typedef struct RptMaterial {
+  double color[3];
+  double index;
+  double roughness;
+  double metallic;
+  double emittance;
+  int32_t transparent; /* bool */
+  int32_t _pad;
+} RptMaterial;
+
+/* ---- Triangle: src/shape/mesh.rs:8-22 (three vertices, three normals) ---- */
+typedef struct RptTriangle {
+  double v1[3], v2[3], v3[3];
+  double n1[3], n2[3], n3[3];
+} RptTriangle;
+
+/* ---- Transformed<T>: src/shape.rs:101-108, the five precomputed fields ---- */
+typedef struct RptTransform {
+  double transform[16];         /* M                                 shape.rs:103 */
+  double linear[9];             /* mat4_to_mat3(M)                   shape.rs:104 */
+  double inverse_transform[16]; /* glm::inverse(M)                   shape.rs:105 */
+  double normal_transform[9];   /* glm::inverse_transpose(linear)    shape.rs:106 */
+  double scale;                 /* linear.determinant()              shape.rs:107 */
+} RptTransform;
+
+/* The closed set of shapes the device understands (the reference's `dyn Shape` is open). */
+enum {
+  RPT_SHAPE_SPHERE = 0, /* src/shape/sphere.rs:9    unit sphere at the origin                 */
+  RPT_SHAPE_PLANE = 1,  /* src/shape/plane.rs:7-13  x . normal = value                        */
+  RPT_SHAPE_CUBE = 2,   /* src/shape/cube.rs:8      unit cube [-0.5,0.5]^3                    */
+  RPT_SHAPE_MESH = 3,   /* src/shape/mesh.rs:102    Mesh = KdTree<Triangle>                   */
+  RPT_SHAPE_GROUP = 4   /* KdTree<Box<dyn Bounded>> (examples/fractal_spheres.rs:45);
+                           children must be SPHERE or CUBE, each optionally Transformed       */
+};
+
+typedef struct RptShape {
+  int32_t kind;        /* RPT_SHAPE_*                                                          */
+  int32_t transformed; /* 1 = wrapped in Transformed<T> (shape.rs:101), xf is valid            */
+  RptTransform xf;
+  double plane_normal[3]; /* PLANE: plane.rs:9  */
+  double plane_value;     /* PLANE: plane.rs:12 */
+  const RptTriangle* triangles; /* MESH: KdTree<Triangle>::objects (kdtree.rs:102)             */
+  uint64_t num_triangles;
+  const struct RptShape* children; /* GROUP: KdTree<Box<dyn Bounded>>::objects                 */
+  uint64_t num_children;
+} RptShape;
+
+/* ---- Object: src/object.rs:10-16 (one shape, one material) ---- */
+typedef struct RptObject {
+  RptShape shape;
+  RptMaterial material;
+} RptObject;
+
+/* ---- Light: src/light.rs:7-19 ---- */
+enum {
+  RPT_LIGHT_POINT = 0,       /* Point(color, location)        */
+  RPT_LIGHT_AMBIENT = 1,     /* Ambient(color)                */
+  RPT_LIGHT_DIRECTIONAL = 2, /* Directional(color, direction) */
+  RPT_LIGHT_OBJECT = 3       /* Object(Object)                */
+};
+
+typedef struct RptLight {
+  int32_t kind;
+  int32_t _pad;
+  double color[3];
+  double vec[3];    /* POINT: location; DIRECTIONAL: direction (not normalised by the caller) */
+  RptObject object; /* OBJECT */
+} RptLight;
+
+/* ---- Environment: src/environment.rs:56-62, Hdri: environment.rs:5-15 ---- */
+enum { RPT_ENV_COLOR = 0, RPT_ENV_HDRI = 1 };
+
+typedef struct RptEnvironment {
+  int32_t kind;
+  int32_t _pad;
+  double color[3];      /* COLOR */
+  uint32_t width;       /* HDRI  */
+  uint32_t height;      /* HDRI  */
+  const double* texels; /* HDRI: width*height*3 doubles, row-major, row 0 = polar angle 0
+                           (environment.rs:14 `buf: Vec<Color>`)                              */
+} RptEnvironment;
+
+/* ---- Scene: src/scene.rs:7-16 ---- */
+typedef struct RptScene {
+  const RptObject* objects;
+  uint64_t num_objects;
+  const RptLight* lights;
+  uint64_t num_lights;
+  RptEnvironment environment;
+} RptScene;
+
+/* ---- Camera: src/camera.rs:8-26 ---- */
+typedef struct RptCamera {
+  double eye[3];
+  double direction[3];
+  double up[3];
+  double fov;
+  double aperture;
+  double focal_distance;
+} RptCamera;
+
+/* Arithmetic modes.  STRICT is the parity mode: IEEE f64, no FMA contraction, true
+ * divisions — the arithmetic of the reference (Rust never contracts).  */
+enum {
+  RPT_PRECISION_F64_STRICT = 0,
+  RPT_PRECISION_F64_FAST = 1 /* f64 with FMA contraction allowed (statistically compared) */
+};
+
+enum {
+  RPT_FLAG_PROFILE_KERNELS = 1u /* bracket every kernel with HIP events (rptgpu_get_stats) */
+};
+
+/* ---- what Renderer carries into sample(): src/renderer.rs:18-42 + the call argument ----
+ * seed / sample_index_base are ADDITIONS: the reference seeds every row from OS entropy
+ * (renderer.rs:121) and is not reproducible.  Random numbers are Philox4x32-10 keyed by
+ * `seed`, counter (pixel index, sample index, draw block): the image does not depend on how
+ * pixels are partitioned over devices. */
+typedef struct RptRenderParams {
+  uint32_t width;       /* renderer.rs:26 */
+  uint32_t height;      /* renderer.rs:29 */
+  uint32_t max_bounces; /* renderer.rs:38 */
+  uint32_t iterations;  /* argument of sample(): paths per pixel in this batch (renderer.rs:117) */
+  double exposure_value; /* renderer.rs:32 */
+  uint64_t seed;
+  uint64_t sample_index_base; /* global index of this batch's first sample                    */
+  /* pixel partition for multi-GPU: the image is cut into tile_width x tile_height tiles,
+     numbered row-major; this call renders tiles with (tile_id % part_count) == part_index and
+     writes 0.0 to every other pixel, so the sum over parts is the full frame.
+     part_count = 0 or 1 renders everything. */
+  uint32_t tile_width;
+  uint32_t tile_height;
+  uint32_t part_index;
+  uint32_t part_count;
+  uint32_t precision_mode; /* RPT_PRECISION_* */
+  uint32_t flags;          /* RPT_FLAG_*      */
+} RptRenderParams;
+
+/* Per-kernel accounting since the last rptgpu_reset_stats (filled when
+ * RPT_FLAG_PROFILE_KERNELS is set; counts are always maintained). */
+enum {
+  RPT_K_RAYGEN = 0,
+  RPT_K_EXTEND = 1, /* closest-hit traversal + intersection      */
+  RPT_K_SHADE = 2,  /* emission, NEE generation, BSDF sampling   */
+  RPT_K_SHADOW = 3, /* shadow-ray traversal                      */
+  RPT_K_RESOLVE = 4,/* nested firefly-clamp fold + accumulation  */
+  RPT_K_COUNT = 8
+};
+
+typedef struct RptStats {
+  double kernel_ms[RPT_K_COUNT];        /* summed HIP-event time per kernel kind             */
+  uint64_t kernel_launches[RPT_K_COUNT];
+  uint64_t extend_rays;  /* closest-hit rays traced  (get_closest_hit, renderer.rs:146)      */
+  uint64_t shadow_rays;  /* shadow rays traced       (renderer.rs:191-196)                   */
+  uint64_t samples;      /* camera paths started                                             */
+  double total_ms;       /* wall time inside rptgpu_render_batch* (host clock)                */
+} RptStats;
+
+typedef struct rptgpu_scene rptgpu_scene; /* opaque */
+
+/* ---- library ---- */
+int rptgpu_abi_version(void);
+const char* rptgpu_strerror(int code);
+/* Detail of the last error on this handle (or of the last failed create when h == NULL);
+ * the pointer stays valid until the next call on the same handle / thread. */
+const char* rptgpu_last_error_detail(const rptgpu_scene* h);
+int rptgpu_device_count(int* out_count);
+
+/* ---- scene hand-off: replaces `&Scene` (scene.rs:7-16) behind Renderer::new
+ * (renderer.rs:46).  Builds the kd-trees by the reference rule (kdtree.rs:235-345), flattens
+ * everything into the device layout and uploads it to `device`.  Unsupported shapes are
+ * rejected here, not at render time. */
+int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out);
+void rptgpu_scene_destroy(rptgpu_scene* h);
+
+/* ---- the hot path: replaces the body of Renderer::sample (renderer.rs:117-129).
+ * Writes out_rgb[(y*width+x)*3+c] = mean over `iterations` paths of pixel (x,y), times
+ * 2^exposure_value (renderer.rs:141); y = 0 is the top row (renderer.rs:134).  The host then
+ * calls Buffer::add_samples(&colors) unchanged (buffer.rs:32-40). */
+int rptgpu_render_batch(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params,
+                        double* out_rgb /* width*height*3, host */);
+
+/* Same, but the result stays in device memory (for an RCCL reduce of the framebuffer by the
+ * caller).  `d_out` is a device pointer to width*height*3 elements, f64 if out_is_f32 == 0
+ * else f32.  `stream` is a hipStream_t (NULL = the library's own stream); the call returns
+ * after the work has been enqueued AND completed on that stream (synchronous). */
+int rptgpu_render_batch_device(rptgpu_scene* h, const RptCamera* camera,
+                               const RptRenderParams* params, void* d_out, int out_is_f32,
+                               void* stream);
+
+/* ---- the closest-hit kernel on its own: replaces Renderer::get_closest_hit
+ * (renderer.rs:211-220) for a batch of rays (host arrays, n rays, xyz interleaved).
+ * out_t = +inf and out_object = -1 on a miss. */
+int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const double* dirs,
+                       uint32_t precision_mode, double* out_t, double* out_normal,
+                       int32_t* out_object);
+
+/* ---- host utility: KdTree::new (kdtree.rs:108-119, construct kdtree.rs:235-345) over n
+ * axis-aligned boxes (p_min xyz, p_max xyz interleaved: 6 doubles per box).  Returns the
+ * flattened tree through malloc'ed arrays the caller releases with rptgpu_free.
+ * Node i: split[i], info[i] = axis (0..2) for inner nodes or 3 for a leaf, a[i] = index of
+ * the left child (right = a[i]+1) for inner nodes or first entry in refs for a leaf,
+ * b[i] = number of refs for a leaf (0 for inner nodes).  Children are visited left first,
+ * nodes are numbered in the order they are created by a depth-first construction. */
+typedef struct RptKdTree {
+  uint64_t num_nodes;
+  uint64_t num_refs;
+  uint32_t max_depth;
+  uint32_t _pad;
+  double* split;
+  uint32_t* info;
+  uint32_t* a;
+  uint32_t* b;
+  uint32_t* refs;
+} RptKdTree;
+int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out);
+void rptgpu_kdtree_free(RptKdTree* tree);
+
+/* ---- accounting ---- */
+int rptgpu_get_stats(const rptgpu_scene* h, RptStats* out);
+int rptgpu_reset_stats(rptgpu_scene* h);
+/* name of kernel kind k as it appears in a rocprofv3 kernel trace */
+const char* rptgpu_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPT_GPU_H */

@@ -1,0 +1,506 @@
+// api.cpp — the C ABI of include/rpt_gpu.h: device memory, the wavefront loop that drives the
+// gfx950 kernels, accounting.  No compute happens on the host; if there is no HIP device every
+// compute entry point returns RPTGPU_E_NO_DEVICE (there is no CPU fallback by design).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rpt_gpu.h"
+#include "device_types.h"
+#include "host_scene.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError {
+  hipError_t e;
+  const char* what;
+  int line;
+};
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t _e = (expr);                             \
+    if (_e != hipSuccess) throw HipError{_e, #expr, __LINE__}; \
+  } while (0)
+
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    if (count <= n && p) return;
+    release();
+    HIP_TRY(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+    n = count;
+  }
+  void upload(const std::vector<T>& v, hipStream_t st) {
+    alloc(v.size());
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+constexpr int MAX_EVENT_PAIRS = 4096;
+
+} // namespace
+
+struct rptgpu_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  // flattened scene on the device
+  DevBuf<rptdev::Inst> insts;
+  DevBuf<rptdev::Tree> trees;
+  DevBuf<rptdev::KdNode> nodes;
+  DevBuf<uint32_t> refs;
+  DevBuf<rptdev::Tri> tris;
+  DevBuf<rptdev::Material> materials;
+  DevBuf<rptdev::Light> lights;
+  DevBuf<double> env_texels;
+  rptdev::Scene dscene{};
+  // workspace
+  DevBuf<double> ray, hit, rec, shadow, accum, out_full;
+  DevBuf<int32_t> hit_obj;
+  DevBuf<uint32_t> draw, queue_a, queue_b, counters, pixels;
+  DevBuf<uint8_t> nrec;
+  uint64_t ws_cap = 0;
+  uint32_t ws_bounces = 0;
+  // cached pixel partition
+  uint32_t part_key[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t npix = 0;
+  // accounting
+  RptStats stats{};
+  std::vector<hipEvent_t> ev_pool;
+  struct Pending { int kind; int e0, e1; };
+  std::vector<Pending> pending;
+  int ev_used = 0;
+  uint64_t target_paths = 4u << 20; // paths in flight per pass
+
+  ~rptgpu_scene() {
+    (void)hipSetDevice(device);
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    insts.release(); trees.release(); nodes.release(); refs.release(); tris.release();
+    materials.release(); lights.release(); env_texels.release();
+    ray.release(); hit.release(); rec.release(); shadow.release(); accum.release(); out_full.release();
+    hit_obj.release(); draw.release(); queue_a.release(); queue_b.release(); counters.release();
+    pixels.release(); nrec.release();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+int fail(rptgpu_scene* h, int code, const std::string& detail) {
+  if (h) h->error = detail;
+  else g_create_error = detail;
+  return code;
+}
+
+int hip_fail(rptgpu_scene* h, const HipError& e) {
+  char buf[512];
+  std::snprintf(buf, sizeof buf, "%s failed at api.cpp:%d: %s", e.what, e.line, hipGetErrorString(e.e));
+  int code = (e.e == hipErrorOutOfMemory) ? RPTGPU_E_OUT_OF_MEMORY
+             : (e.e == hipErrorNoDevice || e.e == hipErrorInvalidDevice || e.e == hipErrorInsufficientDriver)
+                 ? RPTGPU_E_NO_DEVICE
+                 : RPTGPU_E_HIP;
+  return fail(h, code, buf);
+}
+
+const KernelTable* table_for(uint32_t mode) {
+  return mode == RPT_PRECISION_F64_FAST ? &rpt_fast::TABLE : &rpt_strict::TABLE;
+}
+
+// profiling: bracket a launch with two events from a pool; resolved at the end of the call
+struct Bracket {
+  rptgpu_scene* h;
+  int kind;
+  bool on;
+  int e0 = -1;
+  Bracket(rptgpu_scene* h_, int kind_, bool on_) : h(h_), kind(kind_), on(on_) {
+    h->stats.kernel_launches[kind]++;
+    if (!on) return;
+    if (h->ev_used + 2 > MAX_EVENT_PAIRS * 2) { on = false; return; }
+    while ((int)h->ev_pool.size() < h->ev_used + 2) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      h->ev_pool.push_back(e);
+    }
+    e0 = h->ev_used;
+    h->ev_used += 2;
+    HIP_TRY(hipEventRecord(h->ev_pool[e0], h->stream));
+  }
+  void done() {
+    if (!on) return;
+    HIP_TRY(hipEventRecord(h->ev_pool[e0 + 1], h->stream));
+    h->pending.push_back({kind, e0, e0 + 1});
+  }
+};
+
+void drain_events(rptgpu_scene* h) {
+  for (auto& p : h->pending) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[p.e0], h->ev_pool[p.e1]));
+    h->stats.kernel_ms[p.kind] += ms;
+  }
+  h->pending.clear();
+  h->ev_used = 0;
+}
+
+void ensure_partition(rptgpu_scene* h, const RptRenderParams& p) {
+  uint32_t tw = p.tile_width ? p.tile_width : 32, th = p.tile_height ? p.tile_height : 8;
+  uint32_t pc = p.part_count ? p.part_count : 1, pi = p.part_count ? p.part_index : 0;
+  uint32_t key[6] = {p.width, p.height, tw, th, pi, pc};
+  if (std::memcmp(key, h->part_key, sizeof key) == 0 && h->pixels.p) return;
+  std::vector<uint32_t> pix;
+  uint32_t tiles_x = (p.width + tw - 1) / tw;
+  pix.reserve((size_t)p.width * p.height / pc + 1);
+  for (uint32_t y = 0; y < p.height; y++)
+    for (uint32_t x = 0; x < p.width; x++) {
+      uint32_t tile = (y / th) * tiles_x + (x / tw);
+      if (pc <= 1 || tile % pc == pi) pix.push_back(y * p.width + x);
+    }
+  h->pixels.upload(pix, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->npix = (uint32_t)pix.size();
+  std::memcpy(h->part_key, key, sizeof key);
+}
+
+void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
+  if (cap <= h->ws_cap && max_bounces <= h->ws_bounces && h->ray.p) return;
+  cap = std::max(cap, h->ws_cap);
+  max_bounces = std::max(max_bounces, h->ws_bounces);
+  int nl = std::max(1, h->dscene.num_lights);
+  h->ray.alloc(6 * cap);
+  h->hit.alloc(4 * cap);
+  h->hit_obj.alloc(cap);
+  h->draw.alloc(cap);
+  h->nrec.alloc(cap);
+  h->rec.release();
+  h->rec.alloc((uint64_t)(max_bounces + 1) * rptdev::REC_FIELDS * cap);
+  h->shadow.release();
+  h->shadow.alloc((uint64_t)nl * rptdev::SHADOW_FIELDS * cap);
+  h->queue_a.alloc(cap);
+  h->queue_b.alloc(cap);
+  h->counters.alloc(4);
+  h->ws_cap = cap;
+  h->ws_bounces = max_bounces;
+}
+
+rptdev::Camera make_camera(const RptCamera& c) {
+  // Camera::cast_ray derives d and right on every call (camera.rs:66-67); they are constants
+  // of the batch, so they are computed once here with the same expressions.
+  rptdev::Camera d{};
+  std::memcpy(d.eye, c.eye, sizeof d.eye);
+  std::memcpy(d.direction, c.direction, sizeof d.direction);
+  std::memcpy(d.up, c.up, sizeof d.up);
+  d.d = 1.0 / std::tan(c.fov / 2.0);
+  const double* a = c.direction;
+  const double* b = c.up;
+  double cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+  double len = std::sqrt((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
+  for (int k = 0; k < 3; k++) d.right[k] = cr[k] / len;
+  d.aperture = c.aperture;
+  d.focal_distance = c.focal_distance;
+  return d;
+}
+
+int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* p, void* d_out, bool out_f32,
+                double* host_out, hipStream_t user_stream) {
+  if (!h || !camera || !p) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  if (!p->width || !p->height || !p->iterations)
+    return fail(h, RPTGPU_E_INVALID_ARGUMENT, "width, height and iterations must be non-zero");
+  if (p->max_bounces > 254) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "max_bounces > 254");
+  if ((uint64_t)p->width * p->height >= (1ull << 31)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "frame too large");
+  if (p->part_count && p->part_index >= p->part_count)
+    return fail(h, RPTGPU_E_INVALID_ARGUMENT, "part_index >= part_count");
+  if (p->precision_mode > RPT_PRECISION_F64_FAST) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "unknown precision_mode");
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const KernelTable* kt = table_for(p->precision_mode);
+    const bool prof = (p->flags & RPT_FLAG_PROFILE_KERNELS) != 0;
+    ensure_partition(h, *p);
+    const uint32_t npix = h->npix;
+    const uint64_t frame_elems = (uint64_t)p->width * p->height * 3;
+    const size_t out_elem = out_f32 ? sizeof(float) : sizeof(double);
+    void* out = d_out;
+    if (!out) {
+      h->out_full.alloc(frame_elems);
+      out = h->out_full.p;
+    }
+    if (user_stream) HIP_TRY(hipStreamSynchronize(user_stream));
+    HIP_TRY(hipMemsetAsync(out, 0, frame_elems * out_elem, st));
+    if (npix) {
+      uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, h->target_paths / npix));
+      ensure_workspace(h, (uint64_t)npix * s_chunk, p->max_bounces);
+      h->accum.alloc((uint64_t)npix * 3);
+      HIP_TRY(hipMemsetAsync(h->accum.p, 0, (uint64_t)npix * 3 * sizeof(double), st));
+
+      rptdev::PathState ps{};
+      ps.ray = h->ray.p; ps.hit = h->hit.p; ps.hit_obj = h->hit_obj.p; ps.draw = h->draw.p;
+      ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.shadow = h->shadow.p; ps.cap = h->ws_cap;
+      rptdev::Frame fr{};
+      fr.width = p->width; fr.height = p->height; fr.npix = npix; fr.pixels = h->pixels.p;
+      fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
+      rptdev::Camera cam = make_camera(*camera);
+      const bool any_lights = h->dscene.num_lights > 0;
+
+      for (uint32_t s0 = 0; s0 < p->iterations; s0 += s_chunk) {
+        uint32_t sc = std::min(s_chunk, p->iterations - s0);
+        uint32_t n_paths = npix * sc;
+        fr.sample_base = p->sample_index_base + s0;
+        { Bracket b(h, RPT_K_RAYGEN, prof); kt->raygen(st, fr, cam, ps, n_paths); b.done(); }
+        h->stats.samples += n_paths;
+        uint32_t n_active = n_paths;
+        const uint32_t* queue = nullptr; // identity at depth 0
+        uint32_t* next = h->queue_a.p;
+        for (uint32_t depth = 0; depth <= p->max_bounces && n_active; depth++) {
+          { Bracket b(h, RPT_K_EXTEND, prof); kt->extend(st, h->dscene, ps, queue, n_active); b.done(); }
+          h->stats.extend_rays += n_active;
+          HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(uint32_t), st));
+          { Bracket b(h, RPT_K_SHADE, prof);
+            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, h->counters.p); b.done(); }
+          if (any_lights) {
+            Bracket b(h, RPT_K_SHADOW, prof);
+            kt->shadow(st, h->dscene, ps, queue, n_active, depth);
+            b.done();
+          }
+          uint32_t cnt[2] = {0, 0};
+          HIP_TRY(hipMemcpyAsync(cnt, h->counters.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+          h->stats.shadow_rays += (uint64_t)cnt[1] * (uint64_t)h->dscene.num_shadow_lights;
+          n_active = cnt[0];
+          queue = next;
+          next = (next == h->queue_a.p) ? h->queue_b.p : h->queue_a.p;
+        }
+        { Bracket b(h, RPT_K_RESOLVE, prof); kt->resolve(st, fr, ps, sc); b.done(); }
+      }
+      kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
+    }
+    if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, frame_elems * out_elem, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (prof) drain_events(h);
+  } catch (const HipError& e) {
+    h->pending.clear();
+    h->ev_used = 0;
+    return hip_fail(h, e);
+  } catch (const std::bad_alloc&) {
+    return fail(h, RPTGPU_E_OUT_OF_MEMORY, "host allocation failed");
+  } catch (...) {
+    return fail(h, RPTGPU_E_HIP, "unexpected exception");
+  }
+  h->stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return RPTGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rptgpu_abi_version(void) { return RPTGPU_ABI_VERSION; }
+
+const char* rptgpu_strerror(int code) {
+  switch (code) {
+    case RPTGPU_OK: return "ok";
+    case RPTGPU_E_INVALID_ARGUMENT: return "invalid argument";
+    case RPTGPU_E_UNSUPPORTED_SHAPE: return "shape outside the device's closed shape set";
+    case RPTGPU_E_NO_DEVICE: return "no usable HIP device";
+    case RPTGPU_E_HIP: return "HIP runtime error";
+    case RPTGPU_E_OUT_OF_MEMORY: return "out of memory";
+    case RPTGPU_E_TREE_TOO_DEEP: return "kd-tree deeper than the device traversal stack";
+    case RPTGPU_E_UNIMPLEMENTED_SAMPLE: return "Shape::sample is unimplemented for this shape (plane.rs:34-36)";
+    default: return "unknown error";
+  }
+}
+
+const char* rptgpu_last_error_detail(const rptgpu_scene* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int rptgpu_device_count(int* out_count) {
+  if (!out_count) return RPTGPU_E_INVALID_ARGUMENT;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *out_count = 0;
+    return fail(nullptr, RPTGPU_E_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *out_count = n;
+  return RPTGPU_OK;
+}
+
+int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
+  if (!scene || !out) return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  rpthost::FlatScene fs;
+  std::string err;
+  int rc;
+  try {
+    rc = rpthost::flatten_scene(*scene, fs, err); // validates shapes before touching the GPU
+  } catch (const std::bad_alloc&) {
+    return fail(nullptr, RPTGPU_E_OUT_OF_MEMORY, "host allocation failed");
+  } catch (...) {
+    return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "unexpected exception while flattening");
+  }
+  if (rc != RPTGPU_OK) return fail(nullptr, rc, err);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, RPTGPU_E_NO_DEVICE, "no HIP device is visible (hipGetDeviceCount); there is no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "device index out of range");
+  rptgpu_scene* h = new (std::nothrow) rptgpu_scene();
+  if (!h) return fail(nullptr, RPTGPU_E_OUT_OF_MEMORY, "host allocation failed");
+  h->device = device;
+  try {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->insts.upload(fs.insts, h->stream);
+    h->trees.upload(fs.trees, h->stream);
+    h->nodes.upload(fs.nodes, h->stream);
+    h->refs.upload(fs.refs, h->stream);
+    h->tris.upload(fs.tris, h->stream);
+    h->materials.upload(fs.materials, h->stream);
+    h->lights.upload(fs.lights, h->stream);
+    h->env_texels.upload(fs.env_texels, h->stream);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    rptdev::Scene& d = h->dscene;
+    d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p;
+    d.materials = h->materials.p; d.lights = h->lights.p; d.env_texels = h->env_texels.p;
+    std::memcpy(d.env_color, fs.env_color, sizeof d.env_color);
+    d.env_width = fs.env_width; d.env_height = fs.env_height; d.env_kind = fs.env_kind;
+    d.num_objects = fs.num_objects; d.num_lights = (int32_t)fs.lights.size();
+    d.num_shadow_lights = fs.num_shadow_lights;
+    if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) {
+      uint64_t v = std::strtoull(e, nullptr, 10);
+      if (v >= 1024) h->target_paths = v;
+    }
+  } catch (const HipError& e) {
+    int code = hip_fail(nullptr, e);
+    delete h;
+    return code;
+  }
+  *out = h;
+  return RPTGPU_OK;
+}
+
+void rptgpu_scene_destroy(rptgpu_scene* h) { delete h; }
+
+int rptgpu_render_batch(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, double* out_rgb) {
+  if (!out_rgb) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null out_rgb");
+  return render_impl(h, camera, params, nullptr, false, out_rgb, nullptr);
+}
+
+int rptgpu_render_batch_device(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, void* d_out,
+                               int out_is_f32, void* stream) {
+  if (!d_out) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null d_out");
+  return render_impl(h, camera, params, d_out, out_is_f32 != 0, nullptr, (hipStream_t)stream);
+}
+
+int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const double* dirs,
+                       uint32_t precision_mode, double* out_t, double* out_normal, int32_t* out_object) {
+  if (!h || (n && (!origins || !dirs || !out_t || !out_normal || !out_object)))
+    return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  if (precision_mode > RPT_PRECISION_F64_FAST) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "unknown precision_mode");
+  if (!n) return RPTGPU_OK;
+  try {
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    DevBuf<double> d_o, d_d, d_t, d_n;
+    DevBuf<int32_t> d_obj;
+    struct Guard { DevBuf<double>&a, &b, &c, &d; DevBuf<int32_t>& e; ~Guard() { a.release(); b.release(); c.release(); d.release(); e.release(); } } g{d_o, d_d, d_t, d_n, d_obj};
+    d_o.alloc(3 * n); d_d.alloc(3 * n); d_t.alloc(n); d_n.alloc(3 * n); d_obj.alloc(n);
+    HIP_TRY(hipMemcpyAsync(d_o.p, origins, 3 * n * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_d.p, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice, st));
+    table_for(precision_mode)->extend_rays(st, h->dscene, d_o.p, d_d.p, n, d_t.p, d_n.p, d_obj.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_t, d_t.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_normal, d_n.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_object, d_obj.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  } catch (const HipError& e) {
+    return hip_fail(h, e);
+  } catch (...) {
+    return fail(h, RPTGPU_E_HIP, "unexpected exception");
+  }
+  return RPTGPU_OK;
+}
+
+int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out) {
+  if (!out || (n && !boxes)) return RPTGPU_E_INVALID_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  try {
+    std::vector<rpthost::Box> b(n);
+    for (uint64_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        b[i].lo[k] = boxes[6 * i + k];
+        b[i].hi[k] = boxes[6 * i + 3 + k];
+      }
+    rpthost::KdBuild kb;
+    rpthost::kd_build(b, kb);
+    size_t nn = kb.nodes.size(), nr = kb.refs.size();
+    out->split = (double*)std::malloc(std::max<size_t>(nn, 1) * sizeof(double));
+    out->info = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
+    out->a = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
+    out->b = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
+    out->refs = (uint32_t*)std::malloc(std::max<size_t>(nr, 1) * sizeof(uint32_t));
+    if (!out->split || !out->info || !out->a || !out->b || !out->refs) {
+      rptgpu_kdtree_free(out);
+      return RPTGPU_E_OUT_OF_MEMORY;
+    }
+    for (size_t i = 0; i < nn; i++) {
+      out->split[i] = kb.nodes[i].split;
+      out->info[i] = kb.nodes[i].ib & 3u;
+      out->a[i] = kb.nodes[i].a;
+      out->b[i] = kb.nodes[i].ib >> 2;
+    }
+    std::memcpy(out->refs, kb.refs.data(), nr * sizeof(uint32_t));
+    out->num_nodes = nn;
+    out->num_refs = nr;
+    out->max_depth = kb.max_depth;
+  } catch (...) {
+    return RPTGPU_E_OUT_OF_MEMORY;
+  }
+  return RPTGPU_OK;
+}
+
+void rptgpu_kdtree_free(RptKdTree* t) {
+  if (!t) return;
+  std::free(t->split); std::free(t->info); std::free(t->a); std::free(t->b); std::free(t->refs);
+  std::memset(t, 0, sizeof *t);
+}
+
+int rptgpu_get_stats(const rptgpu_scene* h, RptStats* out) {
+  if (!h || !out) return RPTGPU_E_INVALID_ARGUMENT;
+  *out = h->stats;
+  return RPTGPU_OK;
+}
+
+int rptgpu_reset_stats(rptgpu_scene* h) {
+  if (!h) return RPTGPU_E_INVALID_ARGUMENT;
+  std::memset(&h->stats, 0, sizeof h->stats);
+  return RPTGPU_OK;
+}
+
+const char* rptgpu_kernel_name(int k) {
+  switch (k) {
+    case RPT_K_RAYGEN: return "rpt_raygen";
+    case RPT_K_EXTEND: return "rpt_extend";
+    case RPT_K_SHADE: return "rpt_shade";
+    case RPT_K_SHADOW: return "rpt_shadow";
+    case RPT_K_RESOLVE: return "rpt_resolve";
+    default: return "";
+  }
+}
+
+} // extern "C"

@@ -1,0 +1,121 @@
+// device_types.h — the flattened, device-resident scene and the wavefront path state.
+// Shared by the host flattener/API (flatten.cpp, api.cpp) and the gfx950 kernels.
+//
+// Layout rules (MI355X): everything a lane gathers on its own (kd nodes, triangles, group
+// children) is a 16-byte-aligned record so one `global_load_dwordx4` (or a run of them) fetches
+// it; everything a whole wave reads at the same index (top-level objects, lights, materials,
+// trees) is read through uniform addresses and lands in SGPRs via the scalar cache; per-path
+// state is structure-of-arrays indexed by path slot so that consecutive lanes touch
+// consecutive 8-byte words.
+#pragma once
+#include <stdint.h>
+
+namespace rptdev {
+
+constexpr int KD_MAX_STACK = 32; // deepest kd-tree the traversal stack holds
+
+// One kd node: 16 B, one dwordx4 load.  Inner: a = left child (right = a+1), ib = axis (0..2).
+// Leaf: a = first entry in refs[], ib = 3 | (count << 2).
+struct alignas(16) KdNode {
+  double split;
+  uint32_t a;
+  uint32_t ib;
+};
+
+// Triangle exactly as the reference stores it (mesh.rs:8-22): v1 v2 v3 n1 n2 n3, 144 B.
+struct alignas(16) Tri {
+  double v[18];
+};
+
+// A placed shape: a top-level scene object, a light's shape, or a child of a GROUP tree.
+struct alignas(16) Inst {
+  int32_t kind;     // RPT_SHAPE_*
+  int32_t has_xf;   // Transformed<T> wrapper present
+  int32_t tree;     // MESH / GROUP: index into trees[]
+  int32_t material; // top-level objects: index into materials[]
+  double inv[16];   // inverse_transform, column-major (shape.rs:105)
+  double nrm[9];    // normal_transform, column-major (shape.rs:106)
+  double fwd[16];   // transform (shape.rs:103)      — sampling only
+  double lin[9];    // linear (shape.rs:104)         — sampling only
+  double scale;     // determinant (shape.rs:107)    — sampling only
+  double plane[4];  // PLANE: normal xyz, value
+};
+
+struct alignas(16) Tree {
+  uint32_t node_base; // into nodes[]
+  uint32_t ref_base;  // into refs[]
+  uint32_t prim_base; // into tris[] (MESH) or insts[] (GROUP)
+  uint32_t num_prims;
+  double bounds[6];   // p_min xyz, p_max xyz (kdtree.rs:103)
+};
+
+struct alignas(16) Material {
+  double color[3];
+  double index, roughness, metallic, emittance;
+  int32_t transparent;
+  int32_t _pad;
+};
+
+struct alignas(16) Light {
+  int32_t kind; // RPT_LIGHT_*
+  int32_t inst; // OBJECT: index into insts[] of the light's shape
+  double color[3];
+  double vec[3];
+  double mat_color[3]; // OBJECT: material.color
+  double mat_emittance;
+};
+
+struct Scene {
+  const Inst* insts;
+  const Tree* trees;
+  const KdNode* nodes;
+  const uint32_t* refs;
+  const Tri* tris;
+  const Material* materials;
+  const Light* lights;
+  const double* env_texels; // HDRI: width*height*3
+  double env_color[3];
+  uint32_t env_width, env_height;
+  int32_t env_kind;
+  int32_t num_objects; // insts[0..num_objects) are scene.objects in order
+  int32_t num_lights;
+  int32_t num_shadow_lights; // lights that cast a shadow ray (non-ambient)
+};
+
+// camera constants, precomputed on the host exactly as Camera::cast_ray derives them per call
+// (camera.rs:66-67): d = 1/tan(fov/2), right = normalize(direction x up)
+struct Camera {
+  double eye[3], direction[3], up[3], right[3];
+  double d;
+  double aperture, focal_distance;
+};
+
+// Per-pass wavefront state, SoA over path slots (slot = s_local * npix + pixel_local).
+// REC_FIELDS doubles per depth record: A[3], f[3], 1/pdf, |wi.n|  (the nested clamp of
+// renderer.rs:162-167 is folded back-to-front by the resolve kernel).
+constexpr int REC_FIELDS = 8;
+constexpr int SHADOW_FIELDS = 7; // wi[3], dist, contribution[3]
+
+struct PathState {
+  double* ray;       // [6][cap]   ox oy oz dx dy dz
+  double* hit;       // [4][cap]   t nx ny nz
+  int32_t* hit_obj;  // [cap]      object index or -1
+  uint32_t* draw;    // [cap]      Philox draw counter of the path's stream
+  uint8_t* nrec;     // [cap]      number of depth records the path produced (0 = still running)
+  double* rec;       // [max_bounces+1][REC_FIELDS][cap]
+  double* shadow;    // [num_lights][SHADOW_FIELDS][cap]
+  uint64_t cap;      // slots allocated (stride of every array above)
+};
+
+struct Frame {
+  uint32_t width, height;
+  uint32_t npix;            // pixels assigned to this part
+  const uint32_t* pixels;   // [npix] pixel indices y*width+x, ascending
+  uint32_t max_bounces;
+  uint32_t _pad;
+  uint64_t seed;
+  uint64_t sample_base;     // global index of the first sample of this pass
+  double* accum;            // [npix][3] running sum of L_0 over samples
+};
+
+} // namespace rptdev

@@ -1,0 +1,370 @@
+// host_scene.cpp — scene hand-off: kd-tree construction and flattening (host, untimed).
+//
+// Reference behaviour reproduced here (the device then only READS the result):
+//   KdTree::new / construct / median          src/kdtree.rs:108-119, 235-355
+//   Triangle::bounding_box                    src/shape/mesh.rs:40-45
+//   Sphere / Cube bounding boxes              src/shape/sphere.rs:66-73, src/shape/cube.rs:10-17
+//   Transformed::bounding_box (8 corners)     src/shape.rs:153-176
+// Compiled with -ffp-contract=off so the split planes are the same doubles the reference
+// computes (medians are sums of two doubles halved).
+#include "host_scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+
+namespace rpthost {
+
+namespace {
+
+constexpr double SCORE_THRESHOLD = 0.85; // kdtree.rs:6
+
+// median of the multiset `v` as `median(&sorted)` (kdtree.rs:347-355) would return it, without
+// the full sort the reference does: only the two middle order statistics matter.
+double median_of(std::vector<double>& v) {
+  size_t n = v.size();
+  size_t mid = n / 2;
+  std::nth_element(v.begin(), v.begin() + mid, v.end());
+  double hi = v[mid];
+  if (n % 2 == 1) return hi;
+  double lo = *std::max_element(v.begin(), v.begin() + mid);
+  return (hi + lo) / 2.0;
+}
+
+struct Builder {
+  const std::vector<Box>& boxes;
+  KdBuild& out;
+  std::vector<double> xs, ys, zs; // scratch
+
+  void make_leaf(uint32_t id, const std::vector<uint32_t>& idx) {
+    out.nodes[id].split = 0.0;
+    out.nodes[id].a = (uint32_t)out.refs.size();
+    out.nodes[id].ib = 3u | ((uint32_t)idx.size() << 2);
+    out.refs.insert(out.refs.end(), idx.begin(), idx.end());
+  }
+
+  void construct(uint32_t id, std::vector<uint32_t>& idx, uint32_t depth) {
+    out.max_depth = std::max(out.max_depth, depth);
+    size_t n = idx.size();
+    if (n < 16) { // kdtree.rs:236-238
+      make_leaf(id, idx);
+      return;
+    }
+    xs.clear(); ys.clear(); zs.clear();
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i : idx) {
+      const Box& b = boxes[i];
+      xs.push_back(b.lo[0]); xs.push_back(b.hi[0]);
+      ys.push_back(b.lo[1]); ys.push_back(b.hi[1]);
+      zs.push_back(b.lo[2]); zs.push_back(b.hi[2]);
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::fmin(lo[k], b.lo[k]);
+        hi[k] = std::fmax(hi[k], b.hi[k]);
+      }
+    }
+    double m[3] = {median_of(xs), median_of(ys), median_of(zs)}; // kdtree.rs:252-255
+    size_t s[3];
+    for (int dim = 0; dim < 3; dim++) { // partition_score kdtree.rs:257-268
+      size_t left = 0, right = 0;
+      for (uint32_t i : idx) {
+        if (boxes[i].lo[dim] <= m[dim]) left++;
+        if (boxes[i].hi[dim] >= m[dim]) right++;
+      }
+      s[dim] = std::max(left, right);
+    }
+    size_t threshold = (size_t)((double)n * SCORE_THRESHOLD); // kdtree.rs:286
+    if (std::min(std::min(s[0], s[1]), s[2]) >= threshold) {
+      make_leaf(id, idx);
+      return;
+    }
+    int split_dir = -1; // kdtree.rs:291-319
+    double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    if (ex > ey && ex > ez) {
+      if (s[0] < threshold) split_dir = 0;
+    } else if (ey > ez) {
+      if (s[1] < threshold) split_dir = 1;
+    } else if (s[2] < threshold) {
+      split_dir = 2;
+    }
+    if (split_dir == -1) {
+      if (s[0] < s[1] && s[0] < s[2]) split_dir = 0;
+      else if (s[1] < s[2]) split_dir = 1;
+      else split_dir = 2;
+    }
+    std::vector<uint32_t> left, right; // partition kdtree.rs:270-281 (straddlers go to both)
+    for (uint32_t i : idx) {
+      if (boxes[i].lo[split_dir] <= m[split_dir]) left.push_back(i);
+      if (boxes[i].hi[split_dir] >= m[split_dir]) right.push_back(i);
+    }
+    std::vector<uint32_t>().swap(idx); // release before recursing
+    uint32_t l = (uint32_t)out.nodes.size();
+    out.nodes.push_back({});
+    out.nodes.push_back({});
+    out.nodes[id].split = m[split_dir];
+    out.nodes[id].a = l;
+    out.nodes[id].ib = (uint32_t)split_dir;
+    construct(l, left, depth + 1);
+    construct(l + 1, right, depth + 1);
+  }
+};
+
+} // namespace
+
+void kd_build(const std::vector<Box>& boxes, KdBuild& out) {
+  out.nodes.clear();
+  out.refs.clear();
+  out.max_depth = 0;
+  out.nodes.push_back({});
+  std::vector<uint32_t> idx(boxes.size());
+  for (size_t i = 0; i < boxes.size(); i++) idx[i] = (uint32_t)i;
+  Builder b{boxes, out, {}, {}, {}};
+  b.construct(0, idx, 0);
+}
+
+// ------------------------------------------------------------------------- flattening
+namespace {
+
+// column-major 4x4 * (v,1), accumulated column by column (nalgebra gemv order)
+void xf_point(const double* m, const double* v, double* r) {
+  for (int k = 0; k < 3; k++) r[k] = ((m[k] * v[0] + m[4 + k] * v[1]) + m[8 + k] * v[2]) + m[12 + k] * 1.0;
+}
+
+Box merge(const Box& a, const Box& b) { // BoundingBox::merge kdtree.rs:46-51
+  Box r;
+  for (int k = 0; k < 3; k++) {
+    r.lo[k] = std::fmin(a.lo[k], b.lo[k]);
+    r.hi[k] = std::fmax(a.hi[k], b.hi[k]);
+  }
+  return r;
+}
+
+Box empty_box() { // BoundingBox::default kdtree.rs:35-42
+  Box b;
+  for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+  return b;
+}
+
+Box transformed_box(const Box& b, const double* m) { // shape.rs:153-176
+  Box r = empty_box();
+  for (int ix = 0; ix < 2; ix++)
+    for (int iy = 0; iy < 2; iy++)
+      for (int iz = 0; iz < 2; iz++) {
+        double v[3] = {ix ? b.hi[0] : b.lo[0], iy ? b.hi[1] : b.lo[1], iz ? b.hi[2] : b.lo[2]};
+        double c[3];
+        xf_point(m, v, c);
+        Box p;
+        for (int k = 0; k < 3; k++) p.lo[k] = p.hi[k] = c[k];
+        r = merge(r, p);
+      }
+  return r;
+}
+
+struct Flattener {
+  FlatScene& fs;
+  std::string& err;
+  std::map<std::pair<const void*, uint64_t>, int> mesh_cache; // shared meshes (Arc<Mesh>)
+
+  int add_tree(const std::vector<Box>& boxes, uint32_t prim_base) {
+    KdBuild kb;
+    kd_build(boxes, kb);
+    if (kb.max_depth > (uint32_t)rptdev::KD_MAX_STACK) {
+      err = "kd-tree depth " + std::to_string(kb.max_depth) + " exceeds the device stack (" +
+            std::to_string(rptdev::KD_MAX_STACK) + ")";
+      return -1;
+    }
+    fs.max_tree_depth = std::max(fs.max_tree_depth, kb.max_depth);
+    rptdev::Tree t;
+    std::memset(&t, 0, sizeof(t));
+    t.node_base = (uint32_t)fs.nodes.size();
+    t.ref_base = (uint32_t)fs.refs.size();
+    t.prim_base = prim_base;
+    t.num_prims = (uint32_t)boxes.size();
+    Box bounds = empty_box(); // KdTree::new bounds fold kdtree.rs:110-113
+    for (const Box& b : boxes) bounds = merge(bounds, b);
+    for (int k = 0; k < 3; k++) { t.bounds[k] = bounds.lo[k]; t.bounds[3 + k] = bounds.hi[k]; }
+    // child / ref indices stay tree-relative; kernels add node_base / ref_base
+    fs.nodes.insert(fs.nodes.end(), kb.nodes.begin(), kb.nodes.end());
+    fs.refs.insert(fs.refs.end(), kb.refs.begin(), kb.refs.end());
+    fs.trees.push_back(t);
+    return (int)fs.trees.size() - 1;
+  }
+
+  // fills `in` (already placed in fs.insts or a local) from a shape description; returns the
+  // untransformed-or-transformed bounding box through *bbox when the shape is Bounded.
+  int fill_inst(const RptShape& s, rptdev::Inst& in, Box* bbox, bool* bounded, int nesting) {
+    std::memset(&in, 0, sizeof(in));
+    in.kind = s.kind;
+    in.has_xf = s.transformed ? 1 : 0;
+    in.tree = -1;
+    in.material = -1;
+    if (s.transformed) {
+      std::memcpy(in.inv, s.xf.inverse_transform, sizeof(in.inv));
+      std::memcpy(in.nrm, s.xf.normal_transform, sizeof(in.nrm));
+      std::memcpy(in.fwd, s.xf.transform, sizeof(in.fwd));
+      std::memcpy(in.lin, s.xf.linear, sizeof(in.lin));
+      in.scale = s.xf.scale;
+    }
+    Box local = empty_box();
+    bool is_bounded = true;
+    switch (s.kind) {
+      case RPT_SHAPE_SPHERE:
+        for (int k = 0; k < 3; k++) { local.lo[k] = -1.0; local.hi[k] = 1.0; }
+        break;
+      case RPT_SHAPE_CUBE:
+        for (int k = 0; k < 3; k++) { local.lo[k] = -0.5; local.hi[k] = 0.5; }
+        break;
+      case RPT_SHAPE_PLANE:
+        for (int k = 0; k < 3; k++) in.plane[k] = s.plane_normal[k];
+        in.plane[3] = s.plane_value;
+        is_bounded = false;
+        break;
+      case RPT_SHAPE_MESH: {
+        if (nesting > 0) {
+          err = "a Mesh inside KdTree<Box<dyn Bounded>> is not supported yet (SURVEY §8f rank 4)";
+          return RPTGPU_E_UNSUPPORTED_SHAPE;
+        }
+        if (!s.triangles && s.num_triangles) { err = "null triangles"; return RPTGPU_E_INVALID_ARGUMENT; }
+        auto key = std::make_pair((const void*)s.triangles, (uint64_t)s.num_triangles);
+        auto it = mesh_cache.find(key);
+        if (it != mesh_cache.end()) {
+          in.tree = it->second;
+        } else {
+          uint32_t base = (uint32_t)fs.tris.size();
+          std::vector<Box> boxes(s.num_triangles);
+          fs.tris.resize(base + s.num_triangles);
+          for (uint64_t i = 0; i < s.num_triangles; i++) {
+            const RptTriangle& t = s.triangles[i];
+            std::memcpy(fs.tris[base + i].v, &t, sizeof(double) * 18);
+            for (int k = 0; k < 3; k++) { // glm::min3 / max3, mesh.rs:40-45
+              boxes[i].lo[k] = std::fmin(std::fmin(t.v1[k], t.v2[k]), t.v3[k]);
+              boxes[i].hi[k] = std::fmax(std::fmax(t.v1[k], t.v2[k]), t.v3[k]);
+            }
+          }
+          int tr = add_tree(boxes, base);
+          if (tr < 0) return RPTGPU_E_TREE_TOO_DEEP;
+          mesh_cache[key] = tr;
+          in.tree = tr;
+        }
+        const rptdev::Tree& t = fs.trees[in.tree];
+        for (int k = 0; k < 3; k++) { local.lo[k] = t.bounds[k]; local.hi[k] = t.bounds[3 + k]; }
+        break;
+      }
+      case RPT_SHAPE_GROUP: {
+        if (nesting > 0) { err = "nested KdTree<Box<dyn Bounded>>"; return RPTGPU_E_UNSUPPORTED_SHAPE; }
+        if (!s.children && s.num_children) { err = "null children"; return RPTGPU_E_INVALID_ARGUMENT; }
+        std::vector<rptdev::Inst> kids(s.num_children);
+        std::vector<Box> boxes(s.num_children);
+        for (uint64_t i = 0; i < s.num_children; i++) {
+          const RptShape& c = s.children[i];
+          if (c.kind != RPT_SHAPE_SPHERE && c.kind != RPT_SHAPE_CUBE) {
+            err = "KdTree<Box<dyn Bounded>> children must be spheres or cubes (optionally Transformed)";
+            return RPTGPU_E_UNSUPPORTED_SHAPE;
+          }
+          bool b = true;
+          int rc = fill_inst(c, kids[i], &boxes[i], &b, nesting + 1);
+          if (rc != RPTGPU_OK) return rc;
+        }
+        uint32_t base = (uint32_t)fs.insts.size();
+        int tr = add_tree(boxes, base);
+        if (tr < 0) return RPTGPU_E_TREE_TOO_DEEP;
+        group_children.push_back({tr, std::move(kids)});
+        in.tree = tr;
+        const rptdev::Tree& t = fs.trees[tr];
+        for (int k = 0; k < 3; k++) { local.lo[k] = t.bounds[k]; local.hi[k] = t.bounds[3 + k]; }
+        break;
+      }
+      default:
+        err = "unknown shape kind " + std::to_string(s.kind);
+        return RPTGPU_E_UNSUPPORTED_SHAPE;
+    }
+    if (bounded) *bounded = is_bounded;
+    if (bbox && is_bounded) *bbox = s.transformed ? transformed_box(local, s.xf.transform) : local;
+    return RPTGPU_OK;
+  }
+
+  // GROUP children are appended after all top-level / light instances so that
+  // insts[0..num_objects) stay the scene's objects; prim_base is patched afterwards.
+  std::vector<std::pair<int, std::vector<rptdev::Inst>>> group_children;
+};
+
+} // namespace
+
+int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err) {
+  if ((sc.num_objects && !sc.objects) || (sc.num_lights && !sc.lights)) {
+    err = "null objects/lights";
+    return RPTGPU_E_INVALID_ARGUMENT;
+  }
+  Flattener fl{fs, err, {}, {}};
+  fs.num_objects = (int32_t)sc.num_objects;
+  fs.insts.resize(sc.num_objects);
+  for (uint64_t i = 0; i < sc.num_objects; i++) {
+    rptdev::Inst in;
+    int rc = fl.fill_inst(sc.objects[i].shape, in, nullptr, nullptr, 0);
+    if (rc != RPTGPU_OK) return rc;
+    in.material = (int32_t)fs.materials.size();
+    fs.insts[i] = in;
+    rptdev::Material m;
+    std::memset(&m, 0, sizeof(m));
+    const RptMaterial& s = sc.objects[i].material;
+    std::memcpy(m.color, s.color, sizeof(m.color));
+    m.index = s.index; m.roughness = s.roughness; m.metallic = s.metallic;
+    m.emittance = s.emittance; m.transparent = s.transparent ? 1 : 0;
+    fs.materials.push_back(m);
+  }
+  for (uint64_t i = 0; i < sc.num_lights; i++) {
+    const RptLight& l = sc.lights[i];
+    rptdev::Light dl;
+    std::memset(&dl, 0, sizeof(dl));
+    dl.kind = l.kind;
+    dl.inst = -1;
+    std::memcpy(dl.color, l.color, sizeof(dl.color));
+    std::memcpy(dl.vec, l.vec, sizeof(dl.vec));
+    switch (l.kind) {
+      case RPT_LIGHT_POINT: case RPT_LIGHT_DIRECTIONAL: fs.num_shadow_lights++; break;
+      case RPT_LIGHT_AMBIENT: break;
+      case RPT_LIGHT_OBJECT: {
+        fs.num_shadow_lights++;
+        if (l.object.shape.kind == RPT_SHAPE_PLANE) {
+          err = "Light::Object over a Plane: Plane::sample is unimplemented!() (plane.rs:34-36)";
+          return RPTGPU_E_UNIMPLEMENTED_SAMPLE;
+        }
+        rptdev::Inst in;
+        int rc = fl.fill_inst(l.object.shape, in, nullptr, nullptr, 0);
+        if (rc != RPTGPU_OK) return rc;
+        dl.inst = (int32_t)fs.insts.size();
+        fs.insts.push_back(in);
+        std::memcpy(dl.mat_color, l.object.material.color, sizeof(dl.mat_color));
+        dl.mat_emittance = l.object.material.emittance;
+        break;
+      }
+      default: err = "unknown light kind"; return RPTGPU_E_INVALID_ARGUMENT;
+    }
+    fs.lights.push_back(dl);
+  }
+  for (auto& g : fl.group_children) { // now place GROUP children and patch prim_base
+    fs.trees[g.first].prim_base = (uint32_t)fs.insts.size();
+    fs.insts.insert(fs.insts.end(), g.second.begin(), g.second.end());
+  }
+  fs.env_kind = sc.environment.kind;
+  std::memcpy(fs.env_color, sc.environment.color, sizeof(fs.env_color));
+  if (sc.environment.kind == RPT_ENV_HDRI) {
+    if (!sc.environment.texels || !sc.environment.width || !sc.environment.height) {
+      err = "HDRI without texels";
+      return RPTGPU_E_INVALID_ARGUMENT;
+    }
+    fs.env_width = sc.environment.width;
+    fs.env_height = sc.environment.height;
+    size_t n = (size_t)fs.env_width * fs.env_height * 3;
+    // two guard rows/texels: the reference reads (x0+1, y0+1) unguarded (environment.rs:41-49)
+    fs.env_texels.assign(sc.environment.texels, sc.environment.texels + n);
+    fs.env_texels.resize(n + 3 * ((size_t)fs.env_width + 2), 0.0);
+  } else if (sc.environment.kind != RPT_ENV_COLOR) {
+    err = "unknown environment kind";
+    return RPTGPU_E_INVALID_ARGUMENT;
+  }
+  return RPTGPU_OK;
+}
+
+} // namespace rpthost

@@ -1,0 +1,45 @@
+// host_scene.h — host side of rptgpu_scene_create: kd-tree construction by the reference rule
+// and flattening of the boundary's POD scene description into the device layout.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/rpt_gpu.h"
+#include "device_types.h"
+
+namespace rpthost {
+
+struct Box {
+  double lo[3], hi[3];
+};
+
+struct KdBuild {
+  std::vector<rptdev::KdNode> nodes;
+  std::vector<uint32_t> refs;
+  uint32_t max_depth = 0;
+};
+
+// KdTree::new (kdtree.rs:108-119) -> construct (kdtree.rs:235-345), flattened.
+void kd_build(const std::vector<Box>& boxes, KdBuild& out);
+
+struct FlatScene {
+  std::vector<rptdev::Inst> insts;
+  std::vector<rptdev::Tree> trees;
+  std::vector<rptdev::KdNode> nodes;
+  std::vector<uint32_t> refs;
+  std::vector<rptdev::Tri> tris;
+  std::vector<rptdev::Material> materials;
+  std::vector<rptdev::Light> lights;
+  std::vector<double> env_texels;
+  double env_color[3] = {0, 0, 0};
+  uint32_t env_width = 0, env_height = 0;
+  int32_t env_kind = 0;
+  int32_t num_objects = 0;
+  int32_t num_shadow_lights = 0;
+  uint32_t max_tree_depth = 0;
+};
+
+// returns RPTGPU_OK or an error code; `err` explains
+int flatten_scene(const RptScene& scene, FlatScene& out, std::string& err);
+
+} // namespace rpthost

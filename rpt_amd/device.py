@@ -1,0 +1,112 @@
+"""Thin object wrapper over the C ABI (include/rpt_gpu.h): scene upload, the render-batch
+hot path, the closest-hit kernel and the accounting.  Everything here calls into
+`librptgpu.so`; nothing is computed in Python."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+def make_params(width, height, max_bounces, iterations, exposure_value=0.0, seed=0x52505447,
+                sample_index_base=0, tile=(32, 8), part=(0, 1),
+                precision=_abi.RPT_PRECISION_F64_STRICT, flags=0):
+    p = _abi.RptRenderParams()
+    p.width, p.height, p.max_bounces, p.iterations = int(width), int(height), int(max_bounces), int(iterations)
+    p.exposure_value = float(exposure_value)
+    p.seed, p.sample_index_base = int(seed), int(sample_index_base)
+    p.tile_width, p.tile_height = int(tile[0]), int(tile[1])
+    p.part_index, p.part_count = int(part[0]), int(part[1])
+    p.precision_mode, p.flags = int(precision), int(flags)
+    return p
+
+
+def device_count():
+    lib = _abi.load_library()
+    n = C.c_int(0)
+    _abi.check(lib.rptgpu_device_count(C.byref(n)))
+    return n.value
+
+
+class GpuScene:
+    """Owns one `rptgpu_scene*` (device-resident flattened scene + kd-trees)."""
+
+    def __init__(self, scene, device=0):
+        self.lib = _abi.load_library()
+        desc, keep = scene.lower()
+        h = C.c_void_p()
+        _abi.check(self.lib.rptgpu_scene_create(C.byref(desc), int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.rptgpu_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_batch(self, camera, params):
+        """Renderer::sample's output: (H*W, 3) float64 means, row-major, top row first."""
+        out = np.empty((params.height * params.width, 3), dtype=np.float64)
+        cam = camera.lower() if hasattr(camera, "lower") else camera
+        code = self.lib.rptgpu_render_batch(self.handle, C.byref(cam), C.byref(params),
+                                            out.ctypes.data_as(C.POINTER(C.c_double)))
+        _abi.check(code, self.handle)
+        return out
+
+    def render_batch_device(self, camera, params, d_ptr, out_is_f32=False, stream=None):
+        cam = camera.lower() if hasattr(camera, "lower") else camera
+        code = self.lib.rptgpu_render_batch_device(self.handle, C.byref(cam), C.byref(params),
+                                                   C.c_void_p(d_ptr), 1 if out_is_f32 else 0,
+                                                   C.c_void_p(stream or 0))
+        _abi.check(code, self.handle)
+
+    def closest_hit(self, origins, dirs, precision=_abi.RPT_PRECISION_F64_STRICT):
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        n = len(o)
+        t = np.empty(n, dtype=np.float64)
+        nrm = np.empty((n, 3), dtype=np.float64)
+        obj = np.empty(n, dtype=np.int32)
+        PD = C.POINTER(C.c_double)
+        code = self.lib.rptgpu_closest_hit(self.handle, n, o.ctypes.data_as(PD), d.ctypes.data_as(PD),
+                                           int(precision), t.ctypes.data_as(PD), nrm.ctypes.data_as(PD),
+                                           obj.ctypes.data_as(C.POINTER(C.c_int32)))
+        _abi.check(code, self.handle)
+        return t, nrm, obj
+
+    def stats(self):
+        s = _abi.RptStats()
+        _abi.check(self.lib.rptgpu_get_stats(self.handle, C.byref(s)), self.handle)
+        return s
+
+    def reset_stats(self):
+        _abi.check(self.lib.rptgpu_reset_stats(self.handle), self.handle)
+
+
+def kdtree_build(boxes, lib=None, prefix="rptgpu"):
+    """KdTree::new over (n, 6) boxes through the C ABI -> dict of numpy arrays."""
+    lib = lib or _abi.load_library()
+    b = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+    t = _abi.RptKdTree()
+    build = getattr(lib, prefix + "_kdtree_build")
+    free = getattr(lib, prefix + "_kdtree_free")
+    code = build(b.ctypes.data_as(C.POINTER(C.c_double)), len(b), C.byref(t))
+    if code != 0:
+        raise _abi.RptGpuError(code, "kdtree_build")
+    n, r = t.num_nodes, t.num_refs
+    out = {
+        "split": np.ctypeslib.as_array(t.split, (n,)).copy(),
+        "info": np.ctypeslib.as_array(t.info, (n,)).copy(),
+        "a": np.ctypeslib.as_array(t.a, (n,)).copy(),
+        "b": np.ctypeslib.as_array(t.b, (n,)).copy(),
+        "refs": np.ctypeslib.as_array(t.refs, (max(r, 1),)).copy()[:r],
+        "max_depth": t.max_depth,
+    }
+    free(C.byref(t))
+    return out

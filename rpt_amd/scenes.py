@@ -1,0 +1,260 @@
+"""The benchmark scenes of BASELINE.json, written against the rpt builder API exactly as the
+reference's example programs are (reference examples/*.rs, cited per function).  Assets the
+reference downloads (dragon.obj, the ballroom HDRIs) or reads from its own tree
+(wine_glass.obj) are replaced by seeded procedural stand-ins generated here.
+
+Each function returns (scene, camera, defaults) where defaults carries the BASELINE config:
+width, height, max_bounces, num_samples.
+"""
+import math
+
+import numpy as np
+
+from .camera import Camera
+from .color import hex_color
+from .environment import Environment, Hdri
+from .light import Light
+from .material import Material
+from .object import Object
+from .scene import Scene
+from .shape import KdTree, Mesh, cube, plane, polygon, sphere
+
+
+# ----------------------------------------------------------------------------- C1
+def sphere_scene():
+    """examples/sphere.rs:3-35 — 960x540, 2 bounces, 100 spp."""
+    scene = Scene()
+    scene.add(Object(sphere()))  # default red material
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0xAAAAAA))))
+    scene.add(Light.Object(
+        Object(sphere().scale((2.0, 2.0, 2.0)).translate((0.0, 12.0, 0.0)))
+        .material(Material.light(hex_color(0xFFFFFF), 40.0))))
+    camera = Camera.look_at((-2.5, 4.0, 6.5), (0.0, -0.25, 0.0), (0.0, 1.0, 0.0), math.pi / 4.0)
+    return scene, camera, dict(width=960, height=540, max_bounces=2, num_samples=100)
+
+
+# ----------------------------------------------------------------------------- C2
+def cornell():
+    """examples/cornell.rs:9-80 — BASELINE: 1920x1080, 8 bounces, 512 spp."""
+    scene = Scene()
+    camera = Camera(eye=(278.0, 273.0, -800.0), direction=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0), fov=0.686)
+    white = Material.diffuse(hex_color(0xAAAAAA))
+    red = Material.diffuse(hex_color(0xBC0000))
+    green = Material.diffuse(hex_color(0x00BC00))
+    light_mtl = Material.light(hex_color(0xFFFEFA), 100.0)
+    floor = polygon([(0.0, 0.0, 0.0), (0.0, 0.0, 559.2), (556.0, 0.0, 559.2), (556.0, 0.0, 0.0)])
+    ceiling = polygon([(0.0, 548.9, 0.0), (556.0, 548.9, 0.0), (556.0, 548.9, 559.2), (0.0, 548.9, 559.2)])
+    light_rect = polygon([(343.0, 548.8, 227.0), (343.0, 548.8, 332.0), (213.0, 548.8, 332.0), (213.0, 548.8, 227.0)])
+    back_wall = polygon([(0.0, 0.0, 559.2), (0.0, 548.9, 559.2), (556.0, 548.9, 559.2), (556.0, 0.0, 559.2)])
+    right_wall = polygon([(0.0, 0.0, 0.0), (0.0, 548.9, 0.0), (0.0, 548.9, 559.2), (0.0, 0.0, 559.2)])
+    left_wall = polygon([(556.0, 0.0, 0.0), (556.0, 0.0, 559.2), (556.0, 548.9, 559.2), (556.0, 548.9, 0.0)])
+    two_pi = 2.0 * math.pi
+    large_box = (cube().scale((165.0, 330.0, 165.0)).rotate_y(two_pi * (-253.0 / 360.0))
+                 .translate((368.0, 165.0, 351.0)))
+    small_box = (cube().scale((165.0, 165.0, 165.0)).rotate_y(two_pi * (-197.0 / 360.0))
+                 .translate((185.0, 82.5, 169.0)))
+    scene.add(Object(floor).material(white))
+    scene.add(Object(ceiling).material(white))
+    scene.add(Object(back_wall).material(white))
+    scene.add(Object(left_wall).material(red))
+    scene.add(Object(right_wall).material(green))
+    scene.add(Object(large_box).material(white))
+    scene.add(Object(small_box).material(white))
+    scene.add(Light.Object(Object(light_rect).material(light_mtl)))
+    return scene, camera, dict(width=1920, height=1080, max_bounces=8, num_samples=512)
+
+
+# ----------------------------------------------------------------------------- meshes
+def _smooth_mesh(verts, faces):
+    """(V,3) vertices + (F,3) indices -> (F,18) triangle rows with area-weighted vertex normals."""
+    v = np.asarray(verts, dtype=np.float64)
+    f = np.asarray(faces, dtype=np.int64)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    fn = np.cross(b - a, c - a)
+    vn = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(vn, f[:, k], fn)
+    ln = np.sqrt((vn * vn).sum(axis=1, keepdims=True))
+    vn = vn / np.where(ln > 0, ln, 1.0)
+    return np.ascontiguousarray(np.concatenate([a, b, c, vn[f[:, 0]], vn[f[:, 1]], vn[f[:, 2]]], axis=1))
+
+
+def knot_mesh(nu=784, nv=64, seed=0x5EED):
+    """The dragon stand-in: a displaced (2,3) torus-knot tube, nu*nv*2 triangles (default
+    100 352), smooth normals, fitted into a unit-extent box resting at y = -1/3.4 so that the
+    dragon example's `.scale(3.4)` puts it on the floor plane y = -1."""
+    rs = np.random.RandomState(seed)
+    u = np.arange(nu) * (2.0 * math.pi / nu)
+    p, q = 2.0, 3.0
+    r = 2.0 + np.cos(q * u)
+    center = np.stack([r * np.cos(p * u), np.sin(q * u) * 1.2, r * np.sin(p * u)], axis=1)
+    tangent = np.roll(center, -1, axis=0) - np.roll(center, 1, axis=0)
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    up = np.array([0.0, 1.0, 0.0])
+    n1 = np.cross(tangent, up)
+    n1 /= np.linalg.norm(n1, axis=1, keepdims=True)
+    n2 = np.cross(tangent, n1)
+    v = np.arange(nv) * (2.0 * math.pi / nv)
+    # smooth seeded displacement: a few low-frequency harmonics in (u, v)
+    amp = rs.rand(6) * 0.08
+    fu = rs.randint(3, 17, size=6)
+    fv = rs.randint(1, 5, size=6)
+    ph = rs.rand(6) * 2.0 * math.pi
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    radius = 0.42 + sum(amp[k] * np.sin(fu[k] * uu + fv[k] * vv + ph[k]) for k in range(6))
+    pts = (center[:, None, :] + radius[:, :, None] * (np.cos(vv)[:, :, None] * n1[:, None, :]
+                                                        + np.sin(vv)[:, :, None] * n2[:, None, :]))
+    verts = pts.reshape(-1, 3)
+    lo, hi = verts.min(axis=0), verts.max(axis=0)
+    verts = (verts - (lo + hi) / 2.0) / (hi - lo).max()
+    verts[:, 1] += -1.0 / 3.4 - verts[:, 1].min()
+    iu, iv = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    i00 = (iu * nv + iv).ravel()
+    i10 = (((iu + 1) % nu) * nv + iv).ravel()
+    i01 = (iu * nv + (iv + 1) % nv).ravel()
+    i11 = (((iu + 1) % nu) * nv + (iv + 1) % nv).ravel()
+    faces = np.concatenate([np.stack([i00, i10, i11], axis=1), np.stack([i00, i11, i01], axis=1)])
+    return _smooth_mesh(verts, faces)
+
+
+def lathe_glass_mesh(segments=128):
+    """The wine-glass stand-in: a two-sided lathed profile (outer wall up, inner wall down) so
+    rays refract in and out; about 16k triangles at 128 segments, y-up, foot on y = 0."""
+    # (radius, height) going up the outside, then down the inside of the bowl
+    outer = [(0.0, 0.0), (0.9, 0.0), (0.95, 0.04), (0.9, 0.08), (0.3, 0.14), (0.12, 0.25), (0.09, 0.6),
+             (0.09, 1.4), (0.12, 1.75), (0.3, 1.95), (0.62, 2.2), (0.86, 2.55), (0.98, 2.95),
+             (1.02, 3.4), (1.0, 3.85), (0.93, 4.25), (0.86, 4.6)]
+    inner = [(0.83, 4.6), (0.9, 4.25), (0.97, 3.85), (0.99, 3.4), (0.95, 2.97), (0.83, 2.59),
+             (0.6, 2.26), (0.3, 2.03), (0.0, 1.97)]
+
+    def refine(pts, times):
+        for _ in range(times):
+            out = [pts[0]]
+            for a, b in zip(pts[:-1], pts[1:]):
+                out += [((a[0] + b[0]) / 2.0, (a[1] + b[1]) / 2.0), b]
+            pts = out
+        return pts
+
+    prof = np.array(refine(outer + inner, 1), dtype=np.float64)
+    prof[:, 1] *= 0.55  # overall height ~2.5 like the reference's glass in a 10x10 quad
+    prof[:, 0] *= 0.55
+    ang = np.arange(segments) * (2.0 * math.pi / segments)
+    n = len(prof)
+    verts = np.stack([prof[:, None, 0] * np.cos(ang)[None, :],
+                      np.repeat(prof[:, 1:2], segments, axis=1),
+                      prof[:, None, 0] * np.sin(ang)[None, :]], axis=2).reshape(-1, 3)
+    faces = []
+    for i in range(n - 1):
+        for j in range(segments):
+            j2 = (j + 1) % segments
+            a, b, c, d = i * segments + j, i * segments + j2, (i + 1) * segments + j2, (i + 1) * segments + j
+            if prof[i, 0] > 0.0:
+                faces.append((a, c, b))
+            if prof[i + 1, 0] > 0.0:
+                faces.append((a, d, c))
+    return _smooth_mesh(verts, np.array(faces))
+
+
+def synthetic_hdri(width=2048, height=1024, seed=0xBA11):
+    """Stand-in for ballroom_*.hdr: sky/ground gradient + 8 Gaussian lamps (radiance <= 50)
+    + low-amplitude value noise.  f32-rounded like a decoded .hdr (examples/glass.rs:11-13)."""
+    rs = np.random.RandomState(seed)
+    y = (np.arange(height) + 0.5) / height
+    x = (np.arange(width) + 0.5) / width
+    yy, xx = np.meshgrid(y, x, indexing="ij")
+    sky = np.stack([0.35 + 0.4 * (1 - yy), 0.4 + 0.45 * (1 - yy), 0.55 + 0.6 * (1 - yy)], axis=2)
+    ground = np.stack([0.25 * yy, 0.2 * yy, 0.15 * yy], axis=2)
+    img = np.where(yy[:, :, None] < 0.55, sky, ground + 0.08)
+    for _ in range(8):
+        cx, cy = rs.rand(), 0.08 + 0.4 * rs.rand()
+        sig = 0.006 + 0.02 * rs.rand()
+        power = 8.0 + 42.0 * rs.rand()
+        tint = 0.8 + 0.2 * rs.rand(3)
+        dx = np.minimum(np.abs(xx - cx), 1.0 - np.abs(xx - cx))
+        g = np.exp(-(dx * dx + (yy - cy) ** 2) / (2.0 * sig * sig))
+        img = img + power * g[:, :, None] * tint[None, None, :]
+    coarse = rs.rand(height // 32 + 2, width // 32 + 2, 3)
+    noise = np.kron(coarse, np.ones((32, 32, 1)))[:height, :width]
+    img = img * (0.95 + 0.1 * noise)
+    return Hdri(width, height, img.astype(np.float32).astype(np.float64))
+
+
+# ----------------------------------------------------------------------------- C3
+def dragon(nu=784, nv=64):
+    """examples/dragon.rs:30-71 with the knot stand-in for dragon.obj —
+    BASELINE: 1920x1080, 8 bounces, 256 spp."""
+    scene = Scene()
+    mesh = Mesh(knot_mesh(nu, nv))
+    scene.add(Object(mesh.scale((3.4, 3.4, 3.4)).rotate_y(math.pi / 2.0))
+              .material(Material.specular(hex_color(0xB7CA79), 0.1)))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0xAAAAAA))))
+    scene.add(Light.Ambient((0.01, 0.01, 0.01)))
+    scene.add(Light.Object(Object(sphere().scale((2.0, 2.0, 2.0)).translate((0.0, 20.0, 3.0)))
+                           .material(Material.light((1.0, 1.0, 1.0), 160.0))))
+    scene.add(Light.Object(Object(sphere().scale((0.05, 0.05, 0.05)).translate((-1.0, 0.71, 0.0)))
+                           .material(Material.light(hex_color(0xFFAAAA), 400.0))))
+    camera = Camera.look_at((-2.5, 4.0, 6.5), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), math.pi / 6.0)
+    return scene, camera, dict(width=1920, height=1080, max_bounces=8, num_samples=256)
+
+
+# ----------------------------------------------------------------------------- C4
+def fractal_spheres(levels=5):
+    """examples/fractal_spheres.rs:3-76 — BASELINE: 3840x2160, 8 bounces, 1024 spp."""
+    colors = [0x264653, 0x2A9D8F, 0xE9C46A, 0xF4A261, 0xE76F51][:levels]
+    spheres = [[] for _ in colors]
+
+    def gen(p, rad, depth, last_dir):  # fractal_spheres.rs:3-31
+        spheres[depth].append(sphere().scale((rad, rad, rad)).translate(p))
+        if depth == len(spheres) - 1:
+            return
+        disp = rad * 7.0 / 5.0
+        dx = [disp, -disp, 0.0, 0.0, 0.0, 0.0]
+        dy = [0.0, 0.0, disp, -disp, 0.0, 0.0]
+        dz = [0.0, 0.0, 0.0, 0.0, disp, -disp]
+        for i in range(6):
+            if last_dir is None or i != (last_dir ^ 1):
+                gen((p[0] + dx[i], p[1] + dy[i], p[2] + dz[i]), rad * 2.0 / 5.0, depth + 1, i)
+
+    gen((0.0, 0.0, 0.0), 1.0, 0, None)
+    scene = Scene()
+    for i, group in enumerate(spheres):
+        scene.add(Object(KdTree(group)).material(Material.specular(hex_color(colors[i]), 0.25)))
+    scene.add(Object(plane((0.0, 0.0, 1.0), -6.0)).material(Material.diffuse(hex_color(0xFFCCCC))))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    n = math.sqrt((0.0 * 0.0 + 0.65 * 0.65) + 1.0 * 1.0)
+    scene.add(Light.Directional((0.6, 0.6, 0.6), (0.0 / n, -0.65 / n, -1.0 / n)))
+    scene.add(Light.Point((100.0, 100.0, 100.0), (0.0, 5.0, 5.0)))
+    dn = math.sqrt((0.285714 * 0.285714 + 0.5 * 0.5) + 1.0 * 1.0)
+    un = math.sqrt((0.0 + 1.0) + 0.25)
+    camera = Camera(eye=(2.0, 3.5, 7.0), direction=(-0.285714 / dn, -0.5 / dn, -1.0 / dn),
+                    up=(0.0 / un, 1.0 / un, -0.5 / un), fov=math.pi / 6.0)
+    return scene, camera, dict(width=3840, height=2160, max_bounces=8, num_samples=1024)
+
+
+# ----------------------------------------------------------------------------- C5
+def glass(hdri_size=(2048, 1024)):
+    """examples/glass.rs:27-50 (metal + glass unit spheres under an HDRI)."""
+    scene = Scene()
+    scene.environment = Environment.Hdri(synthetic_hdri(*hdri_size))
+    scene.add(Object(sphere().translate((1.1, 0.0, 0.0))).material(Material.metallic_(hex_color(0xFFFFFF), 0.0001)))
+    scene.add(Object(sphere().translate((-1.1, 0.0, 0.0))).material(Material.clear(1.5, 0.0001)))
+    return scene, Camera(), dict(width=3840, height=2160, max_bounces=16, num_samples=4096)
+
+
+def wine_glass(hdri_size=(2048, 1024), segments=128):
+    """examples/wine_glass.rs:27-85 with the lathed stand-in for wine_glass.obj —
+    BASELINE: 3840x2160, 16 bounces, 4096 spp."""
+    scene = Scene()
+    scene.environment = Environment.Hdri(synthetic_hdri(*hdri_size))
+    scene.add(Object(Mesh(lathe_glass_mesh(segments))).material(Material.clear(1.5, 0.0001)))
+    scene.add(Object(polygon([(-5.0, 0.0, -5.0), (-5.0, 0.0, 5.0), (5.0, 0.0, 5.0), (5.0, 0.0, -5.0)]))
+              .material(Material.diffuse(hex_color(0x6F5D48))))
+    scene.add(Light.Object(Object(sphere().scale((3.0, 3.0, 3.0)).translate((11.15, 13.739, -4.9325)))
+                           .material(Material.light(hex_color(0xFFFFFF), 200.0))))
+    eye = (5.530, 4.375, 5.384)
+    camera = Camera.look_at(eye, (eye[0] - 0.6962, eye[1] - 0.3754, eye[2] - 0.6119), (0.0, 1.0, 0.0), 0.6911)
+    return scene, camera, dict(width=3840, height=2160, max_bounces=16, num_samples=4096)
+
+
+SCENES = {"sphere": sphere_scene, "cornell": cornell, "dragon": dragon,
+          "fractal_spheres": fractal_spheres, "glass": glass, "wine_glass": wine_glass}
