@@ -16,6 +16,12 @@
 
 #include "oracle.h"
 
+// exp/ln/atan/sin_cos/acos/atan2: the reference calls the platform libm through Rust's std.
+// Default build: the fdlibm restatement of include/rpt_math.h (pure IEEE arithmetic, so the
+// gfx950 kernels reproduce it bit for bit).  -DORACLE_SYSTEM_LIBM: the host's glibc instead
+// (liboracle_sysm.so) — tests/test_oracle_libm.py shows the two builds agree.
+#include "../include/rpt_math.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cassert>
@@ -47,6 +53,22 @@ inline double signum(double x) {                                 // f64::signum
   return std::signbit(x) ? -1.0 : 1.0;
 }
 inline bool is_normal(double x) { return std::isnormal(x); } // f64::is_normal
+
+#ifdef ORACLE_SYSTEM_LIBM
+inline double m_exp(double x) { return std::exp(x); }
+inline double m_log(double x) { return std::log(x); }
+inline double m_atan(double x) { return std::atan(x); }
+inline void m_sincos(double x, double& s, double& c) { s = std::sin(x); c = std::cos(x); }
+inline double m_acos(double x) { return std::acos(x); }
+inline double m_atan2(double y, double x) { return std::atan2(y, x); }
+#else
+inline double m_exp(double x) { return rpt_exp(x); }
+inline double m_log(double x) { return rpt_log(x); }
+inline double m_atan(double x) { return rpt_atan(x); }
+inline void m_sincos(double x, double& s, double& c) { rpt_sincos_pio2(x, &s, &c); }
+inline double m_acos(double x) { return rpt_acos(x); }
+inline double m_atan2(double y, double x) { return rpt_atan2(y, x); }
+#endif
 
 // ------------------------------------------------------------------ vectors (nalgebra)
 struct V3 {
@@ -664,7 +686,7 @@ V3 bsdf(const RptMaterial& m, V3 n, V3 wo, V3 wi) { // material.rs:125-210
     double n_dot_h = dot(n, h);
     double nh2 = pow2(n_dot_h);
     double m2 = m.roughness * m.roughness;
-    double d = std::exp((nh2 - 1.0) / (m2 * nh2)) / (m2 * PI * nh2 * nh2);
+    double d = m_exp((nh2 - 1.0) / (m2 * nh2)) / (m2 * PI * nh2 * nh2);
     V3 f;
     if (!wi_outside && std::sqrt(1.0 - wo_dot_h * wo_dot_h) * m.index > 1.0) {
       f = one;
@@ -688,7 +710,7 @@ V3 bsdf(const RptMaterial& m, V3 n, V3 wo, V3 wi) { // material.rs:125-210
     double n_dot_h = dot(n, h);
     double nh2 = pow2(n_dot_h);
     double m2 = m.roughness * m.roughness;
-    double d = std::exp((nh2 - 1.0) / (m2 * nh2)) / (m2 * PI * nh2 * nh2);
+    double d = m_exp((nh2 - 1.0) / (m2 * nh2)) / (m2 * PI * nh2 * nh2);
     double f0s = pow2((m.index - 1.0) / (m.index + 1.0));
     V3 f0 = lerp(v3(f0s, f0s, f0s), color, m.metallic);
     V3 f = f0 + (one - f0) * pow5(1.0 - std::fabs(wi_dot_h));
@@ -720,8 +742,9 @@ bool sample_f(const RptMaterial& m, V3 n, V3 wo, Rng& rng, V3& wi, double& pdf) 
   double eta_t = dot(wo, n) > 0.0 ? m.index : 1.0 / m.index;
 
   auto beckmann = [&]() { // :244-254
-    double theta = std::atan(std::sqrt(m2 * -std::log(rng.gen_f64())));
-    double sin_t = std::sin(theta), cos_t = std::cos(theta);
+    double theta = m_atan(std::sqrt(m2 * -m_log(rng.gen_f64())));
+    double sin_t, cos_t;
+    m_sincos(theta, sin_t, cos_t);
     double x, y;
     rng.unit_circle(x, y);
     V3 h = {x * sin_t, y * sin_t, cos_t};
@@ -730,7 +753,7 @@ bool sample_f(const RptMaterial& m, V3 n, V3 wo, Rng& rng, V3& wi, double& pdf) 
   auto beckmann_pdf = [&](V3 h) { // :256-262
     double cos_t = std::fabs(dot(h, n));
     double sin_t = std::sqrt(1.0 - cos_t * cos_t);
-    return (1.0 / (PI * m2 * pow3(cos_t))) * std::exp(-pow2(sin_t / cos_t) / m2);
+    return (1.0 / (PI * m2 * pow3(cos_t))) * m_exp(-pow2(sin_t / cos_t) / m2);
   };
 
   if (rng.gen_bool(f)) { // :264-267
@@ -826,8 +849,8 @@ struct Env {
   V3 get_color(V3 dir_in) const { // environment.rs:25-52, 72-77
     if (kind == RPT_ENV_COLOR) return color;
     V3 dir = normalize(dir_in);
-    double azimuth = std::atan2(dir.z, dir.x) + PI;
-    double polar = std::acos(dir.y);
+    double azimuth = m_atan2(dir.z, dir.x) + PI;
+    double polar = m_acos(dir.y);
     double x = azimuth / TAU * (double)(width - 1);
     double y = polar / PI * (double)(height - 1);
     auto sat_u32 = [](double v) -> uint32_t { // Rust `as u32` saturates, NaN -> 0
@@ -1285,6 +1308,20 @@ int oracle_rng_sample(int kind, double lo, double hi, uint64_t seed, uint32_t pi
   }
   *draw = rng.draw;
   return RPTGPU_OK;
+}
+
+void oracle_math_eval(int fn, uint64_t n, const double* x, const double* y, double* out) {
+  for (uint64_t i = 0; i < n; i++) {
+    switch (fn) {
+      case 0: out[i] = rpt_exp(x[i]); break;
+      case 1: out[i] = rpt_log(x[i]); break;
+      case 2: out[i] = rpt_atan(x[i]); break;
+      case 3: { double s, c; rpt_sincos_pio2(x[i], &s, &c); out[i] = s; break; }
+      case 4: { double s, c; rpt_sincos_pio2(x[i], &s, &c); out[i] = c; break; }
+      case 5: out[i] = rpt_acos(x[i]); break;
+      default: out[i] = rpt_atan2(y[i], x[i]); break;
+    }
+  }
 }
 
 void oracle_hex_color(uint32_t x, double* out3) { // color.rs:10-15

@@ -111,6 +111,10 @@ uint64_t oracle_rng_u64(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t
 int oracle_rng_sample(int kind, double lo, double hi, uint64_t seed, uint32_t pixel,
                       uint64_t sample, uint32_t* draw, double* out2);
 
+/* include/rpt_math.h evaluated on the host: fn 0 exp, 1 log, 2 atan, 3 sin, 4 cos (|x| < 3pi/4),
+ * 5 acos, 6 atan2(y, x) */
+void oracle_math_eval(int fn, uint64_t n, const double* x, const double* y, double* out);
+
 /* color.rs:10-24 */
 void oracle_hex_color(uint32_t x, double* out3);
 void oracle_color_bytes(const double* color3, uint8_t* out3);

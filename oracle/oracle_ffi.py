@@ -225,3 +225,26 @@ def buffer_variance(w, h, batches):
     arrs = [np.ascontiguousarray(b, dtype=np.float64) for b in batches]
     ptrs = (PD * len(arrs))(*[_dp(a) for a in arrs])
     return lib().oracle_buffer_variance(C.c_uint32(w), C.c_uint32(h), C.c_uint32(len(arrs)), ptrs)
+
+
+def math_eval(fn, x, y=None):
+    """include/rpt_math.h on the host: fn 0 exp, 1 log, 2 atan, 3 sin, 4 cos, 5 acos, 6 atan2(y, x)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float64)
+    out = np.empty_like(x)
+    lib().oracle_math_eval(int(fn), C.c_uint64(x.size), _dp(x), _dp(y), _dp(out))
+    return out
+
+
+_sysm = None
+
+
+def sysm_lib():
+    """The same oracle built with the host libm (liboracle_sysm.so)."""
+    global _sysm
+    if _sysm is None:
+        p = os.path.join(HERE, "liboracle_sysm.so")
+        if not os.path.exists(p):
+            build()
+        _sysm = C.CDLL(p)
+    return _sysm

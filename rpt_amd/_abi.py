@@ -120,6 +120,7 @@ SYMBOLS = [
      [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), _VP, C.c_int, _VP]),
     ("rptgpu_closest_hit", C.c_int,
      [_VP, C.c_uint64, _PD, _PD, C.c_uint32, _PD, _PD, C.POINTER(C.c_int32)]),
+    ("rptgpu_eval_math", C.c_int, [_VP, C.c_int, C.c_uint64, _PD, _PD, _PD]),
     ("rptgpu_kdtree_build", C.c_int, [_PD, C.c_uint64, C.POINTER(RptKdTree)]),
     ("rptgpu_kdtree_free", None, [C.POINTER(RptKdTree)]),
     ("rptgpu_get_stats", C.c_int, [_VP, C.POINTER(RptStats)]),

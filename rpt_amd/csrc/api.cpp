@@ -436,6 +436,31 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
   return RPTGPU_OK;
 }
 
+int rptgpu_eval_math(rptgpu_scene* h, int fn, uint64_t n, const double* x, const double* y, double* out) {
+  if (!h || (n && (!x || !out)) || fn < 0 || fn > 6 || (fn == 6 && n && !y))
+    return fail(h, RPTGPU_E_INVALID_ARGUMENT, "bad argument");
+  if (!n) return RPTGPU_OK;
+  DevBuf<double> dx, dy, dout;
+  int rc = RPTGPU_OK;
+  try {
+    HIP_TRY(hipSetDevice(h->device));
+    dx.alloc(n); dy.alloc(n); dout.alloc(n);
+    HIP_TRY(hipMemcpyAsync(dx.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (y) HIP_TRY(hipMemcpyAsync(dy.p, y, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(hipMemsetAsync(dy.p, 0, n * sizeof(double), h->stream));
+    rpt_strict::TABLE.eval_math(h->stream, fn, n, dx.p, dy.p, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } catch (const HipError& e) {
+    rc = hip_fail(h, e);
+  } catch (...) {
+    rc = fail(h, RPTGPU_E_HIP, "unexpected exception");
+  }
+  dx.release(); dy.release(); dout.release();
+  return rc;
+}
+
 int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out) {
   if (!out || (n && !boxes)) return RPTGPU_E_INVALID_ARGUMENT;
   std::memset(out, 0, sizeof *out);

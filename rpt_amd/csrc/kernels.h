@@ -16,6 +16,7 @@ struct KernelTable {
                  uint32_t depth);
   void (*resolve)(hipStream_t, const rptdev::Frame&, const rptdev::PathState&, uint32_t n_samples);
   void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32);
+  void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)

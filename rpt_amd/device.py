@@ -80,6 +80,17 @@ class GpuScene:
         _abi.check(code, self.handle)
         return t, nrm, obj
 
+    def eval_math(self, fn, x, y=None):
+        """include/rpt_math.h evaluated on the device (diagnostics)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        yy = np.ascontiguousarray(y, dtype=np.float64) if y is not None else None
+        out = np.empty_like(x)
+        PD = C.POINTER(C.c_double)
+        code = self.lib.rptgpu_eval_math(self.handle, int(fn), x.size, x.ctypes.data_as(PD),
+                                         yy.ctypes.data_as(PD) if yy is not None else None, out.ctypes.data_as(PD))
+        _abi.check(code, self.handle)
+        return out
+
     def stats(self):
         s = _abi.RptStats()
         _abi.check(self.lib.rptgpu_get_stats(self.handle, C.byref(s)), self.handle)

@@ -3,7 +3,7 @@
 
 Matrices are flat column-major lists, as nalgebra stores them: element (r, c) of a 4x4 is
 m[c*4+r].  These run on the host at scene-build time only (never in the timed path); their
-results travel through the C ABI inside `RptTransform`, so the oracle and the HIP path read
+results travel through the C ABI inside `RptTransform`, so every consumer of the ABI reads
 identical bits whatever rounding happens here.
 """
 import math

@@ -70,6 +70,10 @@ def _smooth_mesh(verts, faces):
     v = np.asarray(verts, dtype=np.float64)
     f = np.asarray(faces, dtype=np.int64)
     a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    # closed surfaces: orient outwards (positive signed volume) so normals leave the solid
+    if float((a * np.cross(b, c)).sum()) < 0.0:
+        f = f[:, [0, 2, 1]]
+        a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
     fn = np.cross(b - a, c - a)
     vn = np.zeros_like(v)
     for k in range(3):

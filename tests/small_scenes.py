@@ -1,0 +1,71 @@
+"""Small variants of the BASELINE configs (same scene code, smaller meshes / HDRIs / frames) used by
+the golden fixtures and the GPU parity tests, plus a `coverage` scene that exercises every shape,
+light kind and camera feature the device supports."""
+import math
+
+import numpy as np
+
+import rpt_amd
+from rpt_amd import (Camera, Environment, KdTree, Light, Material, Mesh, Object, Scene, cube, hex_color,
+                     make_params, plane, polygon, scenes, sphere)
+
+
+def coverage():
+    scene = Scene()
+    scene.environment = Environment.Hdri(scenes.synthetic_hdri(64, 32, seed=5))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0x999999))))
+    scene.add(Object(sphere().scale((0.7, 0.9, 0.7)).translate((-1.6, -0.1, 0.3)))
+              .material(Material.metallic_(hex_color(0xE0B060), 0.15)))
+    scene.add(Object(sphere().translate((1.7, 0.0, -0.4))).material(Material.clear(1.5, 0.05)))
+    scene.add(Object(cube().scale((0.8, 1.6, 0.8)).rotate_y(0.6).rotate_x(0.2).translate((0.2, -0.2, -1.5)))
+              .material(Material.specular(hex_color(0x4060C0), 0.3)))
+    scene.add(Object(cube()).material(Material.transparent_((0.7, 1.0, 0.8), 1.3, 0.2)))
+    scene.add(Object(Mesh(scenes.knot_mesh(24, 6)).scale((1.5, 1.5, 1.5)).translate((0.0, 1.2, 0.5)))
+              .material(Material.specular(hex_color(0xB7CA79), 0.2)))
+    kids = [sphere().scale((0.2, 0.2, 0.2)).translate((math.cos(a) * 2.6, -0.8, math.sin(a) * 2.6))
+            for a in np.linspace(0, 2 * math.pi, 20, endpoint=False)]
+    kids += [cube().scale((0.3, 0.3, 0.3)).rotate_z(0.3 * i).translate((-2.0 + i, 2.2, -1.0)) for i in range(5)]
+    kids += [sphere(), cube()]  # untransformed children too
+    scene.add(Object(KdTree(kids).translate((0.0, 0.0, -0.2))).material(Material.diffuse(hex_color(0xCC6655))))
+    scene.add(Light.Ambient((0.03, 0.03, 0.04)))
+    scene.add(Light.Point((30.0, 28.0, 25.0), (3.0, 4.0, 3.0)))
+    scene.add(Light.Directional((0.4, 0.4, 0.5), (0.3, -1.0, -0.2)))
+    scene.add(Light.Object(Object(sphere().scale((0.5, 0.5, 0.5)).translate((-3.0, 3.5, 1.0)))
+                           .material(Material.light((1.0, 0.9, 0.8), 60.0))))
+    scene.add(Light.Object(Object(cube().scale((0.6, 0.1, 0.6)).translate((2.0, 3.0, 2.0)))
+                           .material(Material.light((0.8, 0.9, 1.0), 40.0))))
+    scene.add(Light.Object(Object(polygon([(-0.5, 3.8, -0.5), (-0.5, 3.8, 0.5), (0.5, 3.8, 0.5), (0.5, 3.8, -0.5)])
+                                  .rotate_z(0.1)).material(Material.light((1.0, 1.0, 1.0), 50.0))))
+    scene.add(Light.Object(Object(KdTree([sphere().scale((0.1, 0.1, 0.1)).translate((0.0, 2.9, 2.0 + 0.3 * i))
+                                          for i in range(3)])).material(Material.light((1.0, 0.6, 0.6), 80.0))))
+    camera = Camera.look_at((0.5, 2.2, 7.0), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 0.7).focus((0.0, 0.0, 0.0), 0.05)
+    return scene, camera
+
+
+def small(name):
+    """-> (scene, camera, params) for the named small config."""
+    if name == "sphere":
+        s, c, d = scenes.sphere_scene()
+        return s, c, make_params(64, 36, 2, 8, seed=101)
+    if name == "cornell":
+        s, c, d = scenes.cornell()
+        return s, c, make_params(64, 36, 8, 8, seed=102)
+    if name == "dragon":
+        s, c, d = scenes.dragon(nu=96, nv=16)
+        return s, c, make_params(64, 36, 4, 4, seed=103)
+    if name == "fractal_spheres":
+        s, c, d = scenes.fractal_spheres()
+        return s, c, make_params(64, 36, 4, 4, seed=104)
+    if name == "glass":
+        s, c, d = scenes.glass(hdri_size=(256, 128))
+        return s, c, make_params(64, 48, 6, 4, seed=105)
+    if name == "wine_glass":
+        s, c, d = scenes.wine_glass(hdri_size=(256, 128), segments=24)
+        return s, c, make_params(64, 36, 8, 4, seed=106)
+    if name == "coverage":
+        s, c = coverage()
+        return s, c, make_params(64, 36, 5, 4, seed=107, exposure_value=0.5)
+    raise KeyError(name)
+
+
+NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage"]

@@ -1,0 +1,100 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/rpt_gpu.h declares;
+host-side validation works without a GPU; compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rpt_amd
+from rpt_amd import _abi
+from rpt_amd.shape import Triangle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "rpt_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rptgpu_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.load_library()
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == {s[0] for s in _abi.SYMBOLS}
+    assert lib.rptgpu_abi_version() == 1
+
+
+def test_struct_sizes_match_header(tmp_path):
+    # compile the header with gcc (as C) and compare sizeof of every struct with the ctypes mirror
+    names = ["RptMaterial", "RptTriangle", "RptTransform", "RptShape", "RptObject", "RptLight",
+             "RptEnvironment", "RptScene", "RptCamera", "RptRenderParams", "RptStats", "RptKdTree"]
+    src = '#include <stdio.h>\n#include "rpt_gpu.h"\nint main(void){' + "".join(
+        'printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}"
+    c = tmp_path / "sz.c"
+    c.write_text(src)
+    exe = tmp_path / "sz"
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    for n, sz in zip(names, sizes):
+        assert C.sizeof(getattr(_abi, n)) == sz, n
+
+
+def test_strerror_and_kernel_names():
+    lib = _abi.load_library()
+    assert lib.rptgpu_strerror(0) == b"ok"
+    assert b"device" in lib.rptgpu_strerror(_abi.RPTGPU_E_NO_DEVICE)
+    assert lib.rptgpu_kernel_name(_abi.RPT_K_EXTEND) == b"rpt_extend"
+    assert lib.rptgpu_kernel_name(_abi.RPT_K_SHADE) == b"rpt_shade"
+
+
+def test_unsupported_shapes_rejected_at_scene_create_without_gpu():
+    # validation happens on the host before the GPU is touched (SURVEY §8b error convention)
+    scene = rpt_amd.Scene()
+    scene.add(rpt_amd.Light.Object(rpt_amd.Object(rpt_amd.plane((0, 1, 0), 0.0))))
+    with pytest.raises(rpt_amd.RptGpuError) as e:
+        rpt_amd.GpuScene(scene)
+    assert e.value.code == _abi.RPTGPU_E_UNIMPLEMENTED_SAMPLE  # plane.rs:34-36 unimplemented!()
+
+    scene = rpt_amd.Scene()
+    inner = rpt_amd.KdTree([rpt_amd.sphere().translate((0, 0, 0))])
+    scene.add(rpt_amd.Object(rpt_amd.KdTree([inner, rpt_amd.sphere()])))
+    with pytest.raises(rpt_amd.RptGpuError) as e:
+        rpt_amd.GpuScene(scene)
+    assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
+
+    with pytest.raises(rpt_amd.RptGpuError):
+        rpt_amd.monomial_surface(1.0, 4.0)
+    with pytest.raises(rpt_amd.RptGpuError):
+        rpt_amd.KdTree([rpt_amd.plane((0, 1, 0), 0.0), rpt_amd.sphere()]).lower([])
+
+
+def test_no_cpu_fallback(gpu_available):
+    if gpu_available:
+        pytest.skip("GPU present")
+    scene, camera, _ = rpt_amd.scenes.sphere_scene()
+    with pytest.raises(rpt_amd.RptGpuError) as e:
+        rpt_amd.GpuScene(scene)
+    assert e.value.code == _abi.RPTGPU_E_NO_DEVICE
+    with pytest.raises(rpt_amd.RptGpuError):
+        rpt_amd.Renderer(scene, camera).width(8).height(8).render()
+
+
+def test_missing_library_is_loud(tmp_path):
+    with pytest.raises(ImportError):
+        _abi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_null_arguments_return_error_codes():
+    lib = _abi.load_library()
+    assert lib.rptgpu_scene_create(None, 0, None) == _abi.RPTGPU_E_INVALID_ARGUMENT
+    assert lib.rptgpu_render_batch(None, None, None, None) == _abi.RPTGPU_E_INVALID_ARGUMENT
+    assert lib.rptgpu_get_stats(None, None) == _abi.RPTGPU_E_INVALID_ARGUMENT
+    assert lib.rptgpu_kdtree_build(None, 5, None) == _abi.RPTGPU_E_INVALID_ARGUMENT
+    lib.rptgpu_scene_destroy(None)  # no-op

@@ -1,0 +1,113 @@
+"""KdTree::new (reference src/kdtree.rs:108-119, 235-355): the product's host builder
+(rptgpu_kdtree_build, nth_element medians) against the oracle's line-by-line restatement
+(full sorts), node by node; and the tree statistics of SURVEY appendix A's rule."""
+import numpy as np
+import pytest
+
+from rpt_amd import _abi, scenes
+from rpt_amd.device import kdtree_build
+
+
+def tri_boxes(rows):
+    v = rows[:, :9].reshape(-1, 3, 3)
+    return np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1)
+
+
+def both(boxes, oracle):
+    a = kdtree_build(boxes, _abi.load_library(), "rptgpu")
+    b = kdtree_build(boxes, oracle.lib(), "oracle")
+    return a, b
+
+
+def assert_same_tree(a, b):
+    assert a["max_depth"] == b["max_depth"]
+    for k in ("split", "info", "a", "b", "refs"):
+        assert a[k].shape == b[k].shape, k
+        assert (a[k] == b[k]).all(), k
+
+
+@pytest.mark.parametrize("n,seed", [(0, 0), (1, 1), (15, 2), (16, 3), (17, 4), (200, 5), (5000, 6)])
+def test_random_boxes(oracle, n, seed):
+    rs = np.random.RandomState(seed)
+    lo = rs.rand(n, 3) * 10
+    boxes = np.concatenate([lo, lo + rs.rand(n, 3) * (0.1 + 2.0 * (seed % 2))], axis=1)
+    a, b = both(boxes, oracle)
+    assert_same_tree(a, b)
+    if n < 16:  # kdtree.rs:236: fewer than 16 objects -> a single leaf
+        assert len(a["split"]) == 1 and a["info"][0] == 3 and a["b"][0] == n
+
+
+def test_degenerate_inputs(oracle):
+    boxes = np.tile(np.array([[0, 0, 0, 1, 1, 1.0]]), (64, 1))  # identical boxes: no split is worth it
+    a, b = both(boxes, oracle)
+    assert_same_tree(a, b)
+    assert len(a["split"]) == 1 and a["b"][0] == 64
+    rs = np.random.RandomState(9)
+    flat = np.concatenate([rs.rand(300, 3), np.zeros((300, 3))], axis=1)
+    flat[:, 3:] = flat[:, :3]
+    flat[:, 1] = flat[:, 4] = 0.5  # all boxes flat in y, many equal coordinates (ties at the median)
+    flat[:, 0] = np.round(flat[:, 0] * 4) / 4
+    flat[:, 3] = flat[:, 0]
+    a, b = both(flat, oracle)
+    assert_same_tree(a, b)
+
+
+def test_mesh_trees(oracle):
+    rows = scenes.knot_mesh(nu=96, nv=16)  # 3072 triangles
+    a, b = both(tri_boxes(rows), oracle)
+    assert_same_tree(a, b)
+    n_leaf = int((a["info"] == 3).sum())
+    assert n_leaf == (len(a["info"]) + 1) // 2  # binary tree
+    assert a["b"][a["info"] == 3].sum() == len(a["refs"])
+    assert len(a["refs"]) >= len(rows)  # straddlers are duplicated (kdtree.rs:270-281)
+    assert set(a["refs"].tolist()) == set(range(len(rows)))  # every triangle referenced
+    rows = scenes.lathe_glass_mesh(48)
+    a, b = both(tri_boxes(rows), oracle)
+    assert_same_tree(a, b)
+
+
+def test_fractal_level_tree_statistics(oracle):
+    # SURVEY appendix A (reference rule on examples/fractal_spheres.rs): level 4 = 750 spheres ->
+    # 255 nodes, depth 7, 1 560 refs; level 3 = 150 -> 63 nodes, depth 5, 328 refs
+    scene, _, _ = scenes.fractal_spheres()
+    stats = []
+    for obj in scene.objects[:5]:
+        boxes = []
+        for s in obj.shape.objects:
+            m = s.transform_m
+            r, c = m[0], (m[12], m[13], m[14])
+            boxes.append([c[0] - r, c[1] - r, c[2] - r, c[0] + r, c[1] + r, c[2] + r])
+        a, b = both(np.array(boxes), oracle)
+        assert_same_tree(a, b)
+        stats.append((len(boxes), len(a["split"]), int(a["max_depth"]), len(a["refs"])))
+    assert stats[4] == (750, 255, 7, 1560)
+    assert stats[3] == (150, 63, 5, 328)
+    assert stats[2] == (30, 7, 2, 56)
+    assert stats[1] == (6, 1, 0, 6) and stats[0] == (1, 1, 0, 1)
+
+
+def test_kd_closest_hit_equals_brute_force(oracle):
+    """Property: the kd-tree answer equals a brute-force loop over the same triangles.  The brute
+    force is the same scene cut into single-leaf meshes (< 16 triangles never split, kdtree.rs:236),
+    which get_closest_hit loops over linearly (renderer.rs:211-220)."""
+    import rpt_amd
+    rows = scenes.knot_mesh(nu=64, nv=12)  # 1536 triangles
+    kd = rpt_amd.Scene()
+    kd.add(rpt_amd.Object(rpt_amd.Mesh(rows)))
+    brute = rpt_amd.Scene()
+    for i in range(0, len(rows), 15):
+        brute.add(rpt_amd.Object(rpt_amd.Mesh(rows[i:i + 15])))
+    rs = np.random.RandomState(11)
+    n = 20000
+    o = rs.randn(n, 3)
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 1.5 * rs.rand(n, 1)  # inside and outside the knot
+    target = rows[rs.randint(0, len(rows), n), :3] + rs.randn(n, 3) * 0.02
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0, n0, ob0 = oracle.OracleScene(kd).closest_hit(o, d)
+    t1, n1, ob1 = oracle.OracleScene(brute).closest_hit(o, d)
+    assert (ob0 >= 0).mean() > 0.3
+    assert ((ob0 >= 0) == (ob1 >= 0)).all()
+    assert (t0 == t1).all()  # same triangle test, same t: bit-equal
+    hit = ob0 >= 0
+    assert (n0[hit] == n1[hit]).all(axis=1).mean() > 0.999  # exact ties may pick the other face
