@@ -120,9 +120,18 @@ struct Counters : OracleCounters {
   }
 };
 thread_local Counters* tl_cnt = nullptr;
+thread_local bool tl_shadow = false; // geometry visited on behalf of a shadow ray (renderer.rs:191)
 #define COUNT(field)            \
   do {                          \
     if (tl_cnt) tl_cnt->field++; \
+  } while (0)
+// geometry counters are kept separately for closest-hit rays and for shadow rays
+#define COUNT_GEO(field)                                   \
+  do {                                                     \
+    if (tl_cnt) {                                          \
+      if (tl_shadow) tl_cnt->field##_sh++;                 \
+      else tl_cnt->field++;                                \
+    }                                                      \
   } while (0)
 
 // ------------------------------------------------------------------ RNG
@@ -281,7 +290,7 @@ struct Shape { // shape.rs:18-25 ; Bounded kdtree.rs:9-12
 
 struct Sphere : Shape { // sphere.rs
   bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override { // :13-45
-    COUNT(n_sphere);
+    COUNT_GEO(n_sphere);
     double a = length2(ray.dir);
     double b = dot(ray.dir, ray.origin);
     double c = length2(ray.origin) - 1.0;
@@ -321,7 +330,7 @@ struct Plane : Shape { // plane.rs
   V3 normal;
   double value;
   bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override { // :17-32
-    COUNT(n_plane);
+    COUNT_GEO(n_plane);
     double cosine = dot(normal, ray.dir);
     if (std::fabs(cosine) < 1e-8) return false;
     double time = (value - dot(normal, ray.origin)) / cosine;
@@ -341,7 +350,7 @@ struct Plane : Shape { // plane.rs
 
 struct Cube : Shape { // cube.rs
   bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override { // :20-72
-    COUNT(n_cube);
+    COUNT_GEO(n_cube);
     double t1[3], t2[3];
     V3 n1[3], n2[3];
     for (int dim = 0; dim < 3; dim++) { // compute_interval :21-33
@@ -400,7 +409,7 @@ struct Triangle : Shape { // mesh.rs:8-22
             {rmax(rmax(v1.x, v2.x), v3_.x), rmax(rmax(v1.y, v2.y), v3_.y), rmax(rmax(v1.z, v2.z), v3_.z)}};
   }
   bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override { // mesh.rs:49-82
-    COUNT(n_tri);
+    COUNT_GEO(n_tri);
     V3 d0 = v2 - v1, d1 = v3_ - v1;
     V3 plane_normal = normalize(cross(d0, d1));
     double cosine = dot(plane_normal, ray.dir);
@@ -441,7 +450,7 @@ struct Transformed : Shape { // shape.rs:101-176
   std::unique_ptr<Shape> shape;
   RptTransform xf;
   bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override { // :128-137
-    COUNT(n_inst);
+    COUNT_GEO(n_inst);
     Ray local; // Ray::apply_transform shape.rs:64-71 (direction NOT renormalised)
     local.origin = mat4_mul(xf.inverse_transform, ray.origin, 1.0);
     local.dir = mat4_mul(xf.inverse_transform, ray.dir, 0.0);
@@ -570,7 +579,7 @@ struct KdTree : Shape { // kdtree.rs:100-144
   }
   BBox bounding_box() const override { return bounds; } // :122-126
   bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override { // :129-136
-    COUNT(n_root);
+    COUNT_GEO(n_root);
     double b_min, b_max;
     bounds.intersect(ray, b_min, b_max);
     if (rmax(b_min, t_min) > rmin(b_max, rec.time)) return false;
@@ -587,15 +596,15 @@ struct KdTree : Shape { // kdtree.rs:100-144
     double b_min, b_max;
     bbox.intersect(ray, b_min, b_max);
     if (node.axis == 3) {
-      COUNT(n_leaf);
+      COUNT_GEO(n_leaf);
       bool result = false;
       for (size_t index : node.indices) {
-        COUNT(n_ref);
+        COUNT_GEO(n_ref);
         if (objects[index]->intersect(ray, t_min, rec)) result = true;
       }
       return result;
     }
-    COUNT(n_inner);
+    COUNT_GEO(n_inner);
     double o = ray.origin[node.axis], d = ray.dir[node.axis];
     double t_split = (node.value - o) / d;
     bool left_first = (o < node.value) || (o == node.value && d <= 0.0);
@@ -928,7 +937,9 @@ struct Tracer {
         COUNT(shadow_rays);
         HitRecord h;
         int obj;
+        tl_shadow = true;
         bool hit = closest_hit({pos, wi}, h, obj);
+        tl_shadow = false;
         if (!hit || h.time > dist_to_light) {
           V3 f = bsdf(material, n, wo, wi);
           color = color + cmul(f, intensity) * dot(wi, n);

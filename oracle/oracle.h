@@ -42,6 +42,10 @@ typedef struct OracleCounters {
   uint64_t n_plane;      /* Plane::intersect calls (plane.rs:17)                           */
   uint64_t n_cube;       /* Cube::intersect calls (cube.rs:20)                             */
   uint64_t rng_draws;    /* next_u64 calls                                                 */
+  /* the same geometry counters for work done on behalf of SHADOW rays (renderer.rs:191-196);
+   * the unsuffixed ones above count closest-hit rays from trace_ray only */
+  uint64_t n_inst_sh, n_root_sh, n_inner_sh, n_leaf_sh, n_ref_sh, n_tri_sh, n_sphere_sh, n_plane_sh,
+      n_cube_sh;
 } OracleCounters;
 
 typedef struct oracle_scene oracle_scene;

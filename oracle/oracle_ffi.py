@@ -20,7 +20,8 @@ PD = C.POINTER(C.c_double)
 class OracleCounters(C.Structure):
     _names = ["samples", "segments", "closest_rays", "shadow_rays", "hits", "misses", "n_inst",
               "n_root", "n_inner", "n_leaf", "n_ref", "n_tri", "n_sphere", "n_plane", "n_cube",
-              "rng_draws"]
+              "rng_draws", "n_inst_sh", "n_root_sh", "n_inner_sh", "n_leaf_sh", "n_ref_sh", "n_tri_sh",
+              "n_sphere_sh", "n_plane_sh", "n_cube_sh"]
     _fields_ = [(n, C.c_uint64) for n in _names]
 
     def as_dict(self):

@@ -61,7 +61,8 @@ class Buffer:
         for s in self.samples:
             d = s - mean
             sq = sq + ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
-        per_pixel = sq / (float(n) - 1.0)
+        with np.errstate(all="ignore"):  # one batch: 0/0 = NaN, as the reference computes
+            per_pixel = sq / (float(n) - 1.0)
         variance = 0.0
         for v in per_pixel.tolist():
             variance += v

@@ -282,6 +282,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           uint32_t cnt[2] = {0, 0};
           HIP_TRY(hipMemcpyAsync(cnt, h->counters.p, sizeof cnt, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
+          if (prof && h->pending.size() >= 256) drain_events(h); // the stream is idle here: cheap
           h->stats.shadow_rays += (uint64_t)cnt[1] * (uint64_t)h->dscene.num_shadow_lights;
           n_active = cnt[0];
           queue = next;
