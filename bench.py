@@ -50,7 +50,9 @@ def algorithmic_bytes(c, env_is_hdri):
     shade = c["hits"] * (SHADE_GEOM + MATERIAL) + c["segments"] * STATE_RW + (c["misses"] * ENV if env_is_hdri else 0)
     resolve = c["segments"] * FOLD_RW + c["samples"] * FB
     raygen = c["samples"] * RAY_IO // 2
-    return {"rpt_raygen": raygen, "rpt_extend": ext, "rpt_shade": shade, "rpt_shadow": sha, "rpt_resolve": resolve}
+    parts = {"rpt_raygen": raygen, "rpt_extend": ext, "rpt_shade": shade, "rpt_shadow": sha, "rpt_resolve": resolve}
+    parts["rpt_paths"] = sum(parts.values())  # the persistent kernel does all of it in one launch
+    return parts
 
 
 def main():
@@ -64,6 +66,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--pipeline", default="persistent", choices=["persistent", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16)
     args = ap.parse_args()
@@ -86,6 +89,7 @@ def main():
     spp = args.spp or cfg["num_samples"]
     precision = _abi.RPT_PRECISION_F64_STRICT if args.mode == "strict" else _abi.RPT_PRECISION_F64_FAST
 
+    pipe_flag = _abi.RPT_FLAG_WAVEFRONT if args.pipeline == "wavefront" else 0
     gpu = rpt_amd.GpuScene(scene, local_rank)
     frame = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
     render_part = D.gpu_render_part(gpu, camera)
@@ -93,7 +97,7 @@ def main():
 
     def step():
         p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=step_no[0] * spp,
-                        precision=precision, flags=_abi.RPT_FLAG_PROFILE_KERNELS)
+                        precision=precision, flags=_abi.RPT_FLAG_PROFILE_KERNELS | pipe_flag)
         D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
         step_no[0] += 1
 
@@ -121,9 +125,10 @@ def main():
     if rank == 0:
         total_samples = float(W) * H * spp * args.steps
         value = total_samples / elapsed / 1e6
-        names = [gpu.lib.rptgpu_kernel_name(k).decode() for k in range(5)]
-        kern_ms = {names[k]: st.kernel_ms[k] for k in range(5)}
-        kern_n = {names[k]: int(st.kernel_launches[k]) for k in range(5)}
+        names = [gpu.lib.rptgpu_kernel_name(k).decode() for k in range(6)]
+        kern_ms = {names[k]: st.kernel_ms[k] for k in range(6)}
+        kern_n = {names[k]: int(st.kernel_launches[k]) for k in range(6)}
+        names = [k for k in names if kern_n[k] > 0]
 
         # visit counts of the reference algorithm for this workload, from the instrumented oracle
         # on a bounded sample (1 spp on 1/8 of the tiles); they scale linearly with samples
@@ -151,7 +156,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                    "alg_bytes_per_sample": sum(bytes_k.values()) / rank_samples,
+                    "alg_bytes_per_sample": bytes_k["rpt_paths"] / rank_samples,
                     "kernels": kernels,
                     "note": "compute/latency-bound f64 scalar work on an L2-resident scene; HBM fraction is low by construction (DESIGN.md)"}
 
@@ -173,7 +178,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d bounces, %d spp per step (BASELINE configs[1]: examples/cornell.rs)"
                                    % (args.scene, W, H, B, spp) if args.scene == "cornell" else
                                    "%s %dx%d, %d bounces, %d spp per step" % (args.scene, W, H, B, spp),
-                       "precision_mode": args.mode, "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
+                       "precision_mode": args.mode, "pipeline": args.pipeline, "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
                        "collective": "RCCL reduce(sum) of the f32 framebuffer to rank 0" if world > 1 else "none",
                        "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1)},
             "roofline": roofline,

@@ -153,7 +153,10 @@ enum {
 };
 
 enum {
-  RPT_FLAG_PROFILE_KERNELS = 1u /* bracket every kernel with HIP events (rptgpu_get_stats) */
+  RPT_FLAG_PROFILE_KERNELS = 1u, /* bracket every kernel with HIP events (rptgpu_get_stats) */
+  RPT_FLAG_WAVEFRONT = 2u        /* use the multi-kernel wavefront pipeline (raygen / extend / shade /
+                                    shadow / resolve, path state in HBM) instead of the default
+                                    persistent per-pixel kernel; both give the same bits */
 };
 
 /* ---- what Renderer carries into sample(): src/renderer.rs:18-42 + the call argument ----
@@ -189,6 +192,7 @@ enum {
   RPT_K_SHADE = 2,  /* emission, NEE generation, BSDF sampling   */
   RPT_K_SHADOW = 3, /* shadow-ray traversal                      */
   RPT_K_RESOLVE = 4,/* nested firefly-clamp fold + accumulation  */
+  RPT_K_PATHS = 5,  /* persistent per-pixel kernel: all of the above in registers */
   RPT_K_COUNT = 8
 };
 

@@ -27,7 +27,8 @@ RPT_LIGHT_POINT, RPT_LIGHT_AMBIENT, RPT_LIGHT_DIRECTIONAL, RPT_LIGHT_OBJECT = ra
 RPT_ENV_COLOR, RPT_ENV_HDRI = range(2)
 RPT_PRECISION_F64_STRICT, RPT_PRECISION_F64_FAST = range(2)
 RPT_FLAG_PROFILE_KERNELS = 1
-RPT_K_RAYGEN, RPT_K_EXTEND, RPT_K_SHADE, RPT_K_SHADOW, RPT_K_RESOLVE = range(5)
+RPT_FLAG_WAVEFRONT = 2
+RPT_K_RAYGEN, RPT_K_EXTEND, RPT_K_SHADE, RPT_K_SHADOW, RPT_K_RESOLVE, RPT_K_PATHS = range(6)
 RPT_K_COUNT = 8
 
 f64 = C.c_double

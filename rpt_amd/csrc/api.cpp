@@ -78,6 +78,9 @@ struct rptgpu_scene {
   DevBuf<uint8_t> nrec;
   uint64_t ws_cap = 0;
   uint32_t ws_bounces = 0;
+  DevBuf<double> prec;                 // persistent kernel: depth records [bounces*8][threads]
+  DevBuf<unsigned long long> pcounters; // [0] closest-hit rays [1] shadow rays
+  int num_cus = 0;
   // cached pixel partition
   uint32_t part_key[6] = {0, 0, 0, 0, 0, 0};
   uint32_t npix = 0;
@@ -96,7 +99,7 @@ struct rptgpu_scene {
     materials.release(); lights.release(); env_texels.release();
     ray.release(); hit.release(); rec.release(); shadow.release(); accum.release(); out_full.release();
     hit_obj.release(); draw.release(); queue_a.release(); queue_b.release(); counters.release();
-    pixels.release(); nrec.release();
+    pixels.release(); nrec.release(); prec.release(); pcounters.release();
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -167,11 +170,15 @@ void ensure_partition(rptgpu_scene* h, const RptRenderParams& p) {
   std::vector<uint32_t> pix;
   uint32_t tiles_x = (p.width + tw - 1) / tw;
   pix.reserve((size_t)p.width * p.height / pc + 1);
-  for (uint32_t y = 0; y < p.height; y++)
-    for (uint32_t x = 0; x < p.width; x++) {
-      uint32_t tile = (y / th) * tiles_x + (x / tw);
-      if (pc <= 1 || tile % pc == pi) pix.push_back(y * p.width + x);
-    }
+  // 8x8-pixel blocks, row-major inside a block: the 64 lanes of a wave start on one compact
+  // block, so their paths see the same part of the scene (coherent traversal, similar lengths)
+  for (uint32_t by = 0; by < p.height; by += 8)
+    for (uint32_t bx = 0; bx < p.width; bx += 8)
+      for (uint32_t y = by; y < std::min(by + 8, p.height); y++)
+        for (uint32_t x = bx; x < std::min(bx + 8, p.width); x++) {
+          uint32_t tile = (y / th) * tiles_x + (x / tw);
+          if (pc <= 1 || tile % pc == pi) pix.push_back(y * p.width + x);
+        }
   h->pixels.upload(pix, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->npix = (uint32_t)pix.size();
@@ -244,7 +251,36 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     }
     if (user_stream) HIP_TRY(hipStreamSynchronize(user_stream));
     HIP_TRY(hipMemsetAsync(out, 0, frame_elems * out_elem, st));
-    if (npix) {
+    const bool wavefront = (p->flags & RPT_FLAG_WAVEFRONT) != 0;
+    if (npix && !wavefront) {
+      // ---- default pipeline: one persistent kernel, the whole path in registers
+      h->accum.alloc((uint64_t)npix * 3);
+      int per_cu = kt->paths_max_blocks_per_cu();
+      uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
+      nblocks = (uint32_t)std::min<uint64_t>(nblocks, ((uint64_t)npix + 63) / 64);
+      uint64_t nthreads = (uint64_t)nblocks * 64;
+      h->prec.alloc(std::max<uint64_t>(1, (uint64_t)p->max_bounces) * rptdev::REC_FIELDS * nthreads);
+      h->counters.alloc(4);
+      h->pcounters.alloc(2);
+      HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 2 * sizeof(unsigned long long), st));
+      rptdev::Frame fr{};
+      fr.width = p->width; fr.height = p->height; fr.npix = npix; fr.pixels = h->pixels.p;
+      fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
+      fr.sample_base = p->sample_index_base;
+      rptdev::Camera cam = make_camera(*camera);
+      { Bracket b(h, RPT_K_PATHS, prof);
+        kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, p->iterations, nblocks);
+        b.done(); }
+      HIP_TRY(hipGetLastError());
+      kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
+      unsigned long long rc[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(rc, h->pcounters.p, sizeof rc, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      h->stats.samples += (uint64_t)npix * p->iterations;
+      h->stats.extend_rays += rc[0];
+      h->stats.shadow_rays += rc[1];
+    } else if (npix) {
       uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, h->target_paths / npix));
       ensure_workspace(h, (uint64_t)npix * s_chunk, p->max_bounces);
       h->accum.alloc((uint64_t)npix * 3);
@@ -366,6 +402,9 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
   try {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    h->num_cus = prop.multiProcessorCount;
     h->insts.upload(fs.insts, h->stream);
     h->trees.upload(fs.trees, h->stream);
     h->nodes.upload(fs.nodes, h->stream);
@@ -525,6 +564,7 @@ const char* rptgpu_kernel_name(int k) {
     case RPT_K_SHADE: return "rpt_shade";
     case RPT_K_SHADOW: return "rpt_shadow";
     case RPT_K_RESOLVE: return "rpt_resolve";
+    case RPT_K_PATHS: return "rpt_paths";
     default: return "";
   }
 }

@@ -79,9 +79,14 @@ def test_closest_hit_bit_equal_to_golden_and_oracle(oracle, built, name):
     assert (n0.view(np.int64) == n1.view(np.int64)).all()
 
 
+PIPELINES = {"persistent": 0, "wavefront": _abi.RPT_FLAG_WAVEFRONT}
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 @pytest.mark.parametrize("name", small_scenes.NAMES)
-def test_render_bit_equal_to_golden(built, name):
+def test_render_bit_equal_to_golden(built, name, pipeline):
     scene, cam, p, g = built(name)
+    p = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=PIPELINES[pipeline])
     img = g.render_batch(cam, p)
     ref = load(name)["image"]
     assert np.isfinite(img).all()
@@ -140,7 +145,8 @@ def test_small_workspace_chunks_give_the_same_image(built, monkeypatch):
     ref = g.render_batch(cam, p)
     monkeypatch.setenv("RPTGPU_TARGET_PATHS", "4096")
     g2 = GpuScene(scene, 0)
-    assert (g2.render_batch(cam, p) == ref).all()
+    pw = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=_abi.RPT_FLAG_WAVEFRONT)
+    assert (g2.render_batch(cam, pw) == ref).all()
     g2.close()
 
 
@@ -189,7 +195,15 @@ def test_full_size_properties_cornell_1080p(oracle):
     st = g.stats()
     assert np.isfinite(full).all() and (full >= 0).all()
     assert st.samples == W * H * 2 and st.extend_rays >= st.samples and st.shadow_rays > 0
+    assert st.kernel_ms[_abi.RPT_K_PATHS] > 0 and st.kernel_launches[_abi.RPT_K_PATHS] == 1
+    # the wavefront pipeline gives the same bits and the same ray counts
+    ext, sh = st.extend_rays, st.shadow_rays
+    g.reset_stats()
+    pw = make_params(W, H, B, 2, seed=77, flags=_abi.RPT_FLAG_PROFILE_KERNELS | _abi.RPT_FLAG_WAVEFRONT)
+    assert (g.render_batch(cam, pw) == full).all()
+    st = g.stats()
     assert all(st.kernel_ms[k] > 0 for k in range(5))
+    assert (st.extend_rays, st.shadow_rays) == (ext, sh)
     # idempotence
     assert (g.render_batch(cam, p) == full).all()
     # partition: 8 interleaved parts sum to the frame
