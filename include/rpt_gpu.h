@@ -266,7 +266,8 @@ int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out);
 void rptgpu_kdtree_free(RptKdTree* tree);
 
 /* ---- diagnostics: evaluate one function of include/rpt_math.h on the DEVICE for n arguments
- * (host arrays).  fn: 0 exp, 1 log, 2 atan, 3 sin, 4 cos (|x| < 3pi/4), 5 acos, 6 atan2(y, x).
+ * (host arrays).  fn: 0 exp, 1 log, 2 atan, 3 sin, 4 cos (|x| < 3pi/4), 5 acos, 6 atan2(y, x),
+ * 7 y / x computed through the kernels' shared-reciprocal division (must equal IEEE y / x).
  * Lets the parity tests show that the kernels' transcendental functions are bit-identical to
  * the host's. */
 int rptgpu_eval_math(rptgpu_scene* h, int fn, uint64_t n, const double* x, const double* y,

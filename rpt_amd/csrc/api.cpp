@@ -67,6 +67,7 @@ struct rptgpu_scene {
   DevBuf<rptdev::KdNode> nodes;
   DevBuf<uint32_t> refs;
   DevBuf<rptdev::Tri> tris;
+  DevBuf<rptdev::TriX> trix;
   DevBuf<rptdev::Material> materials;
   DevBuf<rptdev::Light> lights;
   DevBuf<double> env_texels;
@@ -95,7 +96,7 @@ struct rptgpu_scene {
   ~rptgpu_scene() {
     (void)hipSetDevice(device);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
-    insts.release(); trees.release(); nodes.release(); refs.release(); tris.release();
+    insts.release(); trees.release(); nodes.release(); refs.release(); tris.release(); trix.release();
     materials.release(); lights.release(); env_texels.release();
     ray.release(); hit.release(); rec.release(); shadow.release(); accum.release(); out_full.release();
     hit_obj.release(); draw.release(); queue_a.release(); queue_b.release(); counters.release();
@@ -410,12 +411,13 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->nodes.upload(fs.nodes, h->stream);
     h->refs.upload(fs.refs, h->stream);
     h->tris.upload(fs.tris, h->stream);
+    h->trix.upload(fs.trix, h->stream);
     h->materials.upload(fs.materials, h->stream);
     h->lights.upload(fs.lights, h->stream);
     h->env_texels.upload(fs.env_texels, h->stream);
     HIP_TRY(hipStreamSynchronize(h->stream));
     rptdev::Scene& d = h->dscene;
-    d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p;
+    d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p; d.trix = h->trix.p;
     d.materials = h->materials.p; d.lights = h->lights.p; d.env_texels = h->env_texels.p;
     std::memcpy(d.env_color, fs.env_color, sizeof d.env_color);
     d.env_width = fs.env_width; d.env_height = fs.env_height; d.env_kind = fs.env_kind;
@@ -477,7 +479,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
 }
 
 int rptgpu_eval_math(rptgpu_scene* h, int fn, uint64_t n, const double* x, const double* y, double* out) {
-  if (!h || (n && (!x || !out)) || fn < 0 || fn > 6 || (fn == 6 && n && !y))
+  if (!h || (n && (!x || !out)) || fn < 0 || fn > 7 || (fn >= 6 && n && !y))
     return fail(h, RPTGPU_E_INVALID_ARGUMENT, "bad argument");
   if (!n) return RPTGPU_OK;
   DevBuf<double> dx, dy, dout;

@@ -27,6 +27,17 @@ struct alignas(16) Tri {
   double v[18];
 };
 
+// The per-triangle quantities Triangle::intersect re-derives on every test (mesh.rs:50-51,64-69),
+// computed once on the host with the same IEEE operations (so the bits are the ones the
+// reference computes): plane normal, edge vectors and their dot products.  128 B = 8 dwordx4.
+struct alignas(16) TriX {
+  double pn[3];  // normalize((v2-v1) x (v3-v1))
+  double v1[3];
+  double d0[3];  // v2 - v1
+  double d1[3];  // v3 - v1
+  double d00, d01, d11, denom;
+};
+
 // A placed shape: a top-level scene object, a light's shape, or a child of a GROUP tree.
 struct alignas(16) Inst {
   int32_t kind;     // RPT_SHAPE_*
@@ -70,7 +81,8 @@ struct Scene {
   const Tree* trees;
   const KdNode* nodes;
   const uint32_t* refs;
-  const Tri* tris;
+  const Tri* tris;   // vertices + vertex normals (sampling, shading normals)
+  const TriX* trix;  // same index space: intersection-ready records
   const Material* materials;
   const Light* lights;
   const double* env_texels; // HDRI: width*height*3

@@ -161,6 +161,22 @@ Box transformed_box(const Box& b, const double* m) { // shape.rs:153-176
   return r;
 }
 
+// mesh.rs:50-51 and :64-69, same expression order as the reference (nalgebra dot = (a+b)+c,
+// normalize = component / norm); this file is compiled with -ffp-contract=off
+void fill_trix(const RptTriangle& t, rptdev::TriX& x) {
+  double d0[3], d1[3], c[3];
+  for (int k = 0; k < 3; k++) { d0[k] = t.v2[k] - t.v1[k]; d1[k] = t.v3[k] - t.v1[k]; }
+  c[0] = d0[1] * d1[2] - d0[2] * d1[1];
+  c[1] = d0[2] * d1[0] - d0[0] * d1[2];
+  c[2] = d0[0] * d1[1] - d0[1] * d1[0];
+  double len = std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+  for (int k = 0; k < 3; k++) { x.pn[k] = c[k] / len; x.v1[k] = t.v1[k]; x.d0[k] = d0[k]; x.d1[k] = d1[k]; }
+  x.d00 = (d0[0] * d0[0] + d0[1] * d0[1]) + d0[2] * d0[2];
+  x.d01 = (d0[0] * d1[0] + d0[1] * d1[1]) + d0[2] * d1[2];
+  x.d11 = (d1[0] * d1[0] + d1[1] * d1[1]) + d1[2] * d1[2];
+  x.denom = x.d00 * x.d11 - x.d01 * x.d01;
+}
+
 struct Flattener {
   FlatScene& fs;
   std::string& err;
@@ -234,9 +250,11 @@ struct Flattener {
           uint32_t base = (uint32_t)fs.tris.size();
           std::vector<Box> boxes(s.num_triangles);
           fs.tris.resize(base + s.num_triangles);
+          fs.trix.resize(base + s.num_triangles);
           for (uint64_t i = 0; i < s.num_triangles; i++) {
             const RptTriangle& t = s.triangles[i];
             std::memcpy(fs.tris[base + i].v, &t, sizeof(double) * 18);
+            fill_trix(t, fs.trix[base + i]);
             for (int k = 0; k < 3; k++) { // glm::min3 / max3, mesh.rs:40-45
               boxes[i].lo[k] = std::fmin(std::fmin(t.v1[k], t.v2[k]), t.v3[k]);
               boxes[i].hi[k] = std::fmax(std::fmax(t.v1[k], t.v2[k]), t.v3[k]);

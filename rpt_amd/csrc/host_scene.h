@@ -28,6 +28,7 @@ struct FlatScene {
   std::vector<rptdev::KdNode> nodes;
   std::vector<uint32_t> refs;
   std::vector<rptdev::Tri> tris;
+  std::vector<rptdev::TriX> trix;
   std::vector<rptdev::Material> materials;
   std::vector<rptdev::Light> lights;
   std::vector<double> env_texels;

@@ -58,6 +58,35 @@ def test_device_math_is_bit_identical_to_host(oracle, built):
         assert ((a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))).all(), fn
 
 
+def test_shared_reciprocal_division_is_ieee(built):
+    """The kernels divide through a shared refined reciprocal (kernels.inc `div_r`); it must be the
+    correctly rounded IEEE quotient, bit for bit — numpy's `/` is the reference."""
+    g = built("sphere")[3]
+    rs = np.random.RandomState(17)
+    n = 1 << 22
+
+    def rand_exp(lo, hi, size):
+        m = rs.uniform(1.0, 2.0, size) * rs.choice([-1.0, 1.0], size)
+        return np.ldexp(m, rs.randint(lo, hi, size))
+
+    cases = [(rs.randn(n), rs.randn(n)), (rs.uniform(-600, 600, n), rs.uniform(-1, 1, n)),
+             (rand_exp(-450, 450, n), rand_exp(-450, 450, n)),      # around the fast-path range edges
+             (rand_exp(-1070, 1023, n), rand_exp(-1070, 1023, n)),  # denormals, overflow, underflow
+             (rs.randint(-3, 4, n).astype(float), rs.randint(-3, 4, n).astype(float))]  # zeros, exact cases
+    for k in range(20):  # more volume in the normal range: ~10^8 pairs in total
+        cases.append((rand_exp(-30, 30, n), rand_exp(-30, 30, n)))
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 1.7976931348623157e308, 2.0 ** -400,
+                        2.0 ** 400, 2.0 ** -401, 3.0])
+    yy, xx = np.meshgrid(special, special)
+    cases.append((yy.ravel().copy(), xx.ravel().copy()))
+    with np.errstate(all="ignore"):
+        for y, x in cases:
+            got = g.eval_math(7, x, y)
+            ref = y / x
+            same = (got.view(np.int64) == ref.view(np.int64)) | (np.isnan(got) & np.isnan(ref))
+            assert same.all(), (y[~same][:4], x[~same][:4], got[~same][:4], ref[~same][:4])
+
+
 @pytest.mark.parametrize("name", small_scenes.NAMES)
 def test_closest_hit_bit_equal_to_golden_and_oracle(oracle, built, name):
     scene, cam, p, g = built(name)
