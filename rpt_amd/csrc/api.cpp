@@ -411,13 +411,13 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->nodes.upload(fs.nodes, h->stream);
     h->refs.upload(fs.refs, h->stream);
     h->tris.upload(fs.tris, h->stream);
-    h->trix.upload(fs.trix, h->stream);
+    h->trix.upload(fs.lrec, h->stream);
     h->materials.upload(fs.materials, h->stream);
     h->lights.upload(fs.lights, h->stream);
     h->env_texels.upload(fs.env_texels, h->stream);
     HIP_TRY(hipStreamSynchronize(h->stream));
     rptdev::Scene& d = h->dscene;
-    d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p; d.trix = h->trix.p;
+    d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p; d.lrec = h->trix.p;
     d.materials = h->materials.p; d.lights = h->lights.p; d.env_texels = h->env_texels.p;
     std::memcpy(d.env_color, fs.env_color, sizeof d.env_color);
     d.env_width = fs.env_width; d.env_height = fs.env_height; d.env_kind = fs.env_kind;

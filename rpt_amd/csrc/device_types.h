@@ -82,7 +82,7 @@ struct Scene {
   const KdNode* nodes;
   const uint32_t* refs;
   const Tri* tris;   // vertices + vertex normals (sampling, shading normals)
-  const TriX* trix;  // same index space: intersection-ready records
+  const TriX* lrec;  // intersection-ready records in LEAF order: lrec[j] belongs to refs[j]
   const Material* materials;
   const Light* lights;
   const double* env_texels; // HDRI: width*height*3

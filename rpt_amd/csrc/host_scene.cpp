@@ -262,6 +262,15 @@ struct Flattener {
           }
           int tr = add_tree(boxes, base);
           if (tr < 0) return RPTGPU_E_TREE_TOO_DEEP;
+          // leaf-ordered copies of the intersection records: entry j of refs[] <-> lrec[j], so a
+          // leaf's triangles are one contiguous run of 128-byte lines and need no index gather
+          // (HBM capacity is spent on locality: refs are ~5x the triangle count, kdtree.rs:270-281)
+          {
+            const rptdev::Tree& t = fs.trees[tr];
+            size_t nrefs = fs.refs.size() - t.ref_base;
+            fs.lrec.resize(fs.refs.size());
+            for (size_t j = 0; j < nrefs; j++) fs.lrec[t.ref_base + j] = fs.trix[base + fs.refs[t.ref_base + j]];
+          }
           mesh_cache[key] = tr;
           in.tree = tr;
         }
@@ -365,6 +374,7 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err) {
     fs.trees[g.first].prim_base = (uint32_t)fs.insts.size();
     fs.insts.insert(fs.insts.end(), g.second.begin(), g.second.end());
   }
+  fs.lrec.resize(fs.refs.size()); // GROUP trees own ref slots too (unused records)
   fs.env_kind = sc.environment.kind;
   std::memcpy(fs.env_color, sc.environment.color, sizeof(fs.env_color));
   if (sc.environment.kind == RPT_ENV_HDRI) {

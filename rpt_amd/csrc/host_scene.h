@@ -28,7 +28,8 @@ struct FlatScene {
   std::vector<rptdev::KdNode> nodes;
   std::vector<uint32_t> refs;
   std::vector<rptdev::Tri> tris;
-  std::vector<rptdev::TriX> trix;
+  std::vector<rptdev::TriX> trix; // by triangle index (host-side staging only)
+  std::vector<rptdev::TriX> lrec; // by refs[] position: what the device reads
   std::vector<rptdev::Material> materials;
   std::vector<rptdev::Light> lights;
   std::vector<double> env_texels;
