@@ -154,6 +154,8 @@ enum {
 
 enum {
   RPT_FLAG_PROFILE_KERNELS = 1u, /* bracket every kernel with HIP events (rptgpu_get_stats) */
+  RPT_FLAG_GENERAL_TRAVERSAL = 4u, /* tests: always use the general (box-carrying, scratch-stack)
+                                      kd traversal instead of the compact LDS-stack one */
   RPT_FLAG_WAVEFRONT = 2u        /* use the multi-kernel wavefront pipeline (raygen / extend / shade /
                                     shadow / resolve, path state in HBM) instead of the default
                                     persistent per-pixel kernel; both give the same bits */
@@ -255,7 +257,8 @@ typedef struct RptKdTree {
   uint64_t num_nodes;
   uint64_t num_refs;
   uint32_t max_depth;
-  uint32_t _pad;
+  uint32_t regular; /* 1 if every split plane lies inside its node's cell (rptgpu_kdtree_build only;
+                       the device's compact traversal requires it, otherwise the general one runs) */
   double* split;
   uint32_t* info;
   uint32_t* a;

@@ -1278,7 +1278,7 @@ int oracle_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out) {
   out->num_nodes = split.size();
   out->num_refs = refs.size();
   out->max_depth = max_depth;
-  out->_pad = 0;
+  out->regular = 0; // not computed by the restatement
   out->split = dup(split);
   out->info = dup(info);
   out->a = dup(a);

@@ -28,6 +28,7 @@ RPT_ENV_COLOR, RPT_ENV_HDRI = range(2)
 RPT_PRECISION_F64_STRICT, RPT_PRECISION_F64_FAST = range(2)
 RPT_FLAG_PROFILE_KERNELS = 1
 RPT_FLAG_WAVEFRONT = 2
+RPT_FLAG_GENERAL_TRAVERSAL = 4
 RPT_K_RAYGEN, RPT_K_EXTEND, RPT_K_SHADE, RPT_K_SHADOW, RPT_K_RESOLVE, RPT_K_PATHS = range(6)
 RPT_K_COUNT = 8
 
@@ -101,7 +102,7 @@ class RptStats(C.Structure):
 
 class RptKdTree(C.Structure):
     _fields_ = [("num_nodes", C.c_uint64), ("num_refs", C.c_uint64), ("max_depth", C.c_uint32),
-                ("_pad", C.c_uint32), ("split", C.POINTER(f64)), ("info", C.POINTER(C.c_uint32)),
+                ("regular", C.c_uint32), ("split", C.POINTER(f64)), ("info", C.POINTER(C.c_uint32)),
                 ("a", C.POINTER(C.c_uint32)), ("b", C.POINTER(C.c_uint32)),
                 ("refs", C.POINTER(C.c_uint32))]
 

@@ -253,6 +253,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     if (user_stream) HIP_TRY(hipStreamSynchronize(user_stream));
     HIP_TRY(hipMemsetAsync(out, 0, frame_elems * out_elem, st));
     const bool wavefront = (p->flags & RPT_FLAG_WAVEFRONT) != 0;
+    h->dscene.force_general = (p->flags & RPT_FLAG_GENERAL_TRAVERSAL) ? 1 : 0;
     if (npix && !wavefront) {
       // ---- default pipeline: one persistent kernel, the whole path in registers
       h->accum.alloc((uint64_t)npix * 3);
@@ -535,6 +536,7 @@ int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out) {
     out->num_nodes = nn;
     out->num_refs = nr;
     out->max_depth = kb.max_depth;
+    out->regular = kb.regular ? 1u : 0u;
   } catch (...) {
     return RPTGPU_E_OUT_OF_MEMORY;
   }

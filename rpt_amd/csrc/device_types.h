@@ -13,6 +13,7 @@
 namespace rptdev {
 
 constexpr int KD_MAX_STACK = 32; // deepest kd-tree the traversal stack holds
+constexpr int KD_LDS_LEVELS = 12; // stack levels the persistent kernel keeps in LDS (rest: scratch)
 
 // One kd node: 16 B, one dwordx4 load.  Inner: a = left child (right = a+1), ib = axis (0..2).
 // Leaf: a = first entry in refs[], ib = 3 | (count << 2).
@@ -58,6 +59,8 @@ struct alignas(16) Tree {
   uint32_t prim_base; // into tris[] (MESH) or insts[] (GROUP)
   uint32_t num_prims;
   double bounds[6];   // p_min xyz, p_max xyz (kdtree.rs:103)
+  uint32_t regular;   // 1: every split lies inside its cell -> the compact traversal is exact
+  uint32_t _pad[3];
 };
 
 struct alignas(16) Material {
@@ -92,6 +95,8 @@ struct Scene {
   int32_t num_objects; // insts[0..num_objects) are scene.objects in order
   int32_t num_lights;
   int32_t num_shadow_lights; // lights that cast a shadow ray (non-ambient)
+  int32_t force_general;     // tests: always take the general (box-carrying) traversal
+  int32_t _pad;
 };
 
 // camera constants, precomputed on the host exactly as Camera::cast_ray derives them per call

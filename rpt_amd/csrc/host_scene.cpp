@@ -45,7 +45,9 @@ struct Builder {
     out.refs.insert(out.refs.end(), idx.begin(), idx.end());
   }
 
-  void construct(uint32_t id, std::vector<uint32_t>& idx, uint32_t depth) {
+  // cell = the node's box as the reference derives it while traversing: the root bounds cut by the
+  // ancestors' split planes (BoundingBox::split, kdtree.rs:71-86)
+  void construct(uint32_t id, std::vector<uint32_t>& idx, uint32_t depth, Box cell) {
     out.max_depth = std::max(out.max_depth, depth);
     size_t n = idx.size();
     if (n < 16) { // kdtree.rs:236-238
@@ -105,8 +107,14 @@ struct Builder {
     out.nodes[id].split = m[split_dir];
     out.nodes[id].a = l;
     out.nodes[id].ib = (uint32_t)split_dir;
-    construct(l, left, depth + 1);
-    construct(l + 1, right, depth + 1);
+    // the median of the primitives' box edges can fall outside the cell (straddlers reach beyond
+    // it); the device's compact traversal assumes it does not and is disabled for such trees
+    if (!(m[split_dir] >= cell.lo[split_dir] && m[split_dir] <= cell.hi[split_dir])) out.regular = false;
+    Box cl = cell, cr = cell;
+    cl.hi[split_dir] = m[split_dir];
+    cr.lo[split_dir] = m[split_dir];
+    construct(l, left, depth + 1, cl);
+    construct(l + 1, right, depth + 1, cr);
   }
 };
 
@@ -116,11 +124,20 @@ void kd_build(const std::vector<Box>& boxes, KdBuild& out) {
   out.nodes.clear();
   out.refs.clear();
   out.max_depth = 0;
+  out.regular = true;
   out.nodes.push_back({});
   std::vector<uint32_t> idx(boxes.size());
-  for (size_t i = 0; i < boxes.size(); i++) idx[i] = (uint32_t)i;
+  Box root;
+  for (int k = 0; k < 3; k++) { root.lo[k] = INFINITY; root.hi[k] = -INFINITY; }
+  for (size_t i = 0; i < boxes.size(); i++) {
+    idx[i] = (uint32_t)i;
+    for (int k = 0; k < 3; k++) {
+      root.lo[k] = std::fmin(root.lo[k], boxes[i].lo[k]);
+      root.hi[k] = std::fmax(root.hi[k], boxes[i].hi[k]);
+    }
+  }
   Builder b{boxes, out, {}, {}, {}};
-  b.construct(0, idx, 0);
+  b.construct(0, idx, 0, root);
 }
 
 // ------------------------------------------------------------------------- flattening
@@ -197,6 +214,7 @@ struct Flattener {
     t.ref_base = (uint32_t)fs.refs.size();
     t.prim_base = prim_base;
     t.num_prims = (uint32_t)boxes.size();
+    t.regular = kb.regular ? 1u : 0u;
     Box bounds = empty_box(); // KdTree::new bounds fold kdtree.rs:110-113
     for (const Box& b : boxes) bounds = merge(bounds, b);
     for (int k = 0; k < 3; k++) { t.bounds[k] = bounds.lo[k]; t.bounds[3 + k] = bounds.hi[k]; }

@@ -17,6 +17,7 @@ struct KdBuild {
   std::vector<rptdev::KdNode> nodes;
   std::vector<uint32_t> refs;
   uint32_t max_depth = 0;
+  bool regular = true; // every split plane lies inside its node's cell
 };
 
 // KdTree::new (kdtree.rs:108-119) -> construct (kdtree.rs:235-345), flattened.

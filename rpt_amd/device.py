@@ -118,6 +118,7 @@ def kdtree_build(boxes, lib=None, prefix="rptgpu"):
         "b": np.ctypeslib.as_array(t.b, (n,)).copy(),
         "refs": np.ctypeslib.as_array(t.refs, (max(r, 1),)).copy()[:r],
         "max_depth": t.max_depth,
+        "regular": t.regular,
     }
     free(C.byref(t))
     return out

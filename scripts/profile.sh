@@ -6,13 +6,14 @@
 set -u
 TAG=${1:-r01}
 SPP=${2:-32}
+EXTRA="${3:-}"
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --spp $SPP --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --spp $SPP --no-cpu-baseline $EXTRA"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
-PCMD="python $REPO/bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline"
+PCMD="python $REPO/bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline $EXTRA"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- $PCMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o bench -- $PCMD > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq -o bench -- $PCMD > $OUT/pmc_sq.log 2>&1

@@ -108,7 +108,9 @@ def test_closest_hit_bit_equal_to_golden_and_oracle(oracle, built, name):
     assert (n0.view(np.int64) == n1.view(np.int64)).all()
 
 
-PIPELINES = {"persistent": 0, "wavefront": _abi.RPT_FLAG_WAVEFRONT}
+PIPELINES = {"persistent": 0, "wavefront": _abi.RPT_FLAG_WAVEFRONT,
+             "persistent-general-traversal": _abi.RPT_FLAG_GENERAL_TRAVERSAL,
+             "wavefront-general-traversal": _abi.RPT_FLAG_WAVEFRONT | _abi.RPT_FLAG_GENERAL_TRAVERSAL}
 
 
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))

