@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
-    ap.add_argument("--pipeline", default="persistent", choices=["persistent", "wavefront"])
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16)
     args = ap.parse_args()
@@ -89,7 +89,7 @@ def main():
     spp = args.spp or cfg["num_samples"]
     precision = _abi.RPT_PRECISION_F64_STRICT if args.mode == "strict" else _abi.RPT_PRECISION_F64_FAST
 
-    pipe_flag = _abi.RPT_FLAG_WAVEFRONT if args.pipeline == "wavefront" else 0
+    pipe_flag = {"auto": 0, "persistent": _abi.RPT_FLAG_PERSISTENT, "wavefront": _abi.RPT_FLAG_WAVEFRONT}[args.pipeline]
     gpu = rpt_amd.GpuScene(scene, local_rank)
     frame = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
     render_part = D.gpu_render_part(gpu, camera)
@@ -178,7 +178,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d bounces, %d spp per step (BASELINE configs[1]: examples/cornell.rs)"
                                    % (args.scene, W, H, B, spp) if args.scene == "cornell" else
                                    "%s %dx%d, %d bounces, %d spp per step" % (args.scene, W, H, B, spp),
-                       "precision_mode": args.mode, "pipeline": args.pipeline, "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
+                       "precision_mode": args.mode, "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")), "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
                        "collective": "RCCL reduce(sum) of the f32 framebuffer to rank 0" if world > 1 else "none",
                        "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1)},
             "roofline": roofline,

@@ -156,9 +156,13 @@ enum {
   RPT_FLAG_PROFILE_KERNELS = 1u, /* bracket every kernel with HIP events (rptgpu_get_stats) */
   RPT_FLAG_GENERAL_TRAVERSAL = 4u, /* tests: always use the general (box-carrying, scratch-stack)
                                       kd traversal instead of the compact LDS-stack one */
-  RPT_FLAG_WAVEFRONT = 2u        /* use the multi-kernel wavefront pipeline (raygen / extend / shade /
-                                    shadow / resolve, path state in HBM) instead of the default
-                                    persistent per-pixel kernel; both give the same bits */
+  RPT_FLAG_WAVEFRONT = 2u,       /* force the multi-kernel wavefront pipeline (raygen / extend / shade /
+                                    shadow / resolve; path state in HBM, lean 4-waves/SIMD traversal
+                                    kernels with LDS stacks) */
+  RPT_FLAG_PERSISTENT = 8u       /* force the persistent per-pixel kernel (whole path in registers).
+                                    With neither flag the library picks: wavefront when the scene has
+                                    real kd-trees (depth >= 3: traversal latency dominates and wants
+                                    occupancy), persistent otherwise.  Both give the same bits. */
 };
 
 /* ---- what Renderer carries into sample(): src/renderer.rs:18-42 + the call argument ----

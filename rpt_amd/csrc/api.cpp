@@ -82,6 +82,7 @@ struct rptgpu_scene {
   DevBuf<double> prec;                 // persistent kernel: depth records [bounces*8][threads]
   DevBuf<unsigned long long> pcounters; // [0] closest-hit rays [1] shadow rays
   int num_cus = 0;
+  bool prefer_wavefront = false; // scene has real kd-trees: traversal-latency bound
   // cached pixel partition
   uint32_t part_key[6] = {0, 0, 0, 0, 0, 0};
   uint32_t npix = 0;
@@ -252,7 +253,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     }
     if (user_stream) HIP_TRY(hipStreamSynchronize(user_stream));
     HIP_TRY(hipMemsetAsync(out, 0, frame_elems * out_elem, st));
-    const bool wavefront = (p->flags & RPT_FLAG_WAVEFRONT) != 0;
+    const bool wavefront = (p->flags & RPT_FLAG_WAVEFRONT)    ? true
+                           : (p->flags & RPT_FLAG_PERSISTENT) ? false
+                                                              : h->prefer_wavefront;
     h->dscene.force_general = (p->flags & RPT_FLAG_GENERAL_TRAVERSAL) ? 1 : 0;
     if (npix && !wavefront) {
       // ---- default pipeline: one persistent kernel, the whole path in registers
@@ -407,6 +410,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     h->num_cus = prop.multiProcessorCount;
+    h->prefer_wavefront = fs.max_tree_depth >= 3;
     h->insts.upload(fs.insts, h->stream);
     h->trees.upload(fs.trees, h->stream);
     h->nodes.upload(fs.nodes, h->stream);

@@ -108,8 +108,8 @@ def test_closest_hit_bit_equal_to_golden_and_oracle(oracle, built, name):
     assert (n0.view(np.int64) == n1.view(np.int64)).all()
 
 
-PIPELINES = {"persistent": 0, "wavefront": _abi.RPT_FLAG_WAVEFRONT,
-             "persistent-general-traversal": _abi.RPT_FLAG_GENERAL_TRAVERSAL,
+PIPELINES = {"auto": 0, "persistent": _abi.RPT_FLAG_PERSISTENT, "wavefront": _abi.RPT_FLAG_WAVEFRONT,
+             "persistent-general-traversal": _abi.RPT_FLAG_PERSISTENT | _abi.RPT_FLAG_GENERAL_TRAVERSAL,
              "wavefront-general-traversal": _abi.RPT_FLAG_WAVEFRONT | _abi.RPT_FLAG_GENERAL_TRAVERSAL}
 
 
@@ -226,7 +226,7 @@ def test_full_size_properties_cornell_1080p(oracle):
     st = g.stats()
     assert np.isfinite(full).all() and (full >= 0).all()
     assert st.samples == W * H * 2 and st.extend_rays >= st.samples and st.shadow_rays > 0
-    assert st.kernel_ms[_abi.RPT_K_PATHS] > 0 and st.kernel_launches[_abi.RPT_K_PATHS] == 1
+    assert st.kernel_ms[_abi.RPT_K_PATHS] > 0 and st.kernel_launches[_abi.RPT_K_PATHS] == 1  # auto -> persistent here
     # the wavefront pipeline gives the same bits and the same ray counts
     ext, sh = st.extend_rays, st.shadow_rays
     g.reset_stats()
