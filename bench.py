@@ -69,15 +69,23 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last step's reduced f32 frame (.npy)")
+    ap.add_argument("--fixed-samples", action="store_true", help="every step renders the same samples (tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RPT_BENCH_BACKEND=gloo lets the N>1 logic be exercised with several ranks on ONE GPU
+    # (ranks share device local_rank % device_count); the driver's runs use nccl = RCCL.
+    backend = os.environ.get("RPT_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "--gpus must match the launcher's world size"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -96,7 +104,7 @@ def main():
     step_no = [0]
 
     def step():
-        p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=step_no[0] * spp,
+        p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=0 if args.fixed_samples else step_no[0] * spp,
                         precision=precision, flags=_abi.RPT_FLAG_PROFILE_KERNELS | pipe_flag)
         D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
         step_no[0] += 1
@@ -122,6 +130,8 @@ def main():
         elapsed = float(t.item())
     st = gpu.stats()
 
+    if rank == 0 and args.dump_frame:
+        np.save(args.dump_frame, frame.cpu().numpy())
     if rank == 0:
         total_samples = float(W) * H * spp * args.steps
         value = total_samples / elapsed / 1e6

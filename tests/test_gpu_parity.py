@@ -272,3 +272,29 @@ def test_error_paths_on_device(built):
     img = ge.render_batch(rpt_amd.Camera(), make_params(16, 8, 3, 2))
     assert (img == np.array([0.25, 0.5, 1.0])).all()
     ge.close()
+
+
+def test_bench_two_ranks_equal_one_rank(tmp_path):
+    """bench.py's N>1 path on the real GPU: two ranks (gloo stands in for RCCL, both on device 0)
+    shard the tiles and reduce; the reduced f32 frame equals the single-rank frame bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--spp", "4", "--width", "320", "--height", "180", "--no-cpu-baseline",
+              "--fixed-samples"]
+    one = str(tmp_path / "one.npy")
+    two = str(tmp_path / "two.npy")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-frame", one] + common,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, RPT_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--dump-frame", two] + common, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape == (320 * 180 * 3,) and (a == b).all() and a.max() > 0
