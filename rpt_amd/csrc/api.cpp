@@ -266,9 +266,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       uint64_t nthreads = (uint64_t)nblocks * 64;
       h->prec.alloc(std::max<uint64_t>(1, (uint64_t)p->max_bounces) * rptdev::REC_FIELDS * nthreads);
       h->counters.alloc(4);
-      h->pcounters.alloc(2);
+      h->pcounters.alloc(16);
       HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
-      HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 2 * sizeof(unsigned long long), st));
+      HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
       rptdev::Frame fr{};
       fr.width = p->width; fr.height = p->height; fr.npix = npix; fr.pixels = h->pixels.p;
       fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
@@ -279,9 +279,15 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         b.done(); }
       HIP_TRY(hipGetLastError());
       kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
-      unsigned long long rc[2] = {0, 0};
+      unsigned long long rc[16] = {0};
       HIP_TRY(hipMemcpyAsync(rc, h->pcounters.p, sizeof rc, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
+      if (std::getenv("RPTGPU_PRINT_PHASES")) { // only meaningful with a -DRPT_PHASE_TIMERS build
+        unsigned long long tot = 0;
+        for (int i = 2; i < 10; i++) tot += rc[i];
+        const char* nm[8] = {"fetch", "raygen", "closest_hit", "illuminate", "visible", "nee_bsdf", "sample_f", "bsdf+rec+fold"};
+        for (int i = 0; i < 8 && tot; i++) std::fprintf(stderr, "phase %-14s %6.2f %%\n", nm[i], 100.0 * rc[2 + i] / tot);
+      }
       h->stats.samples += (uint64_t)npix * p->iterations;
       h->stats.extend_rays += rc[0];
       h->stats.shadow_rays += rc[1];
