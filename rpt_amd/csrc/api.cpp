@@ -83,6 +83,11 @@ struct rptgpu_scene {
   DevBuf<unsigned long long> pcounters; // [0] closest-hit rays [1] shadow rays
   int num_cus = 0;
   bool prefer_wavefront = false; // scene has real kd-trees: traversal-latency bound
+  // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
+  std::vector<uint8_t> obj_deep, obj_tris, light_casts;
+  bool has_deep = false;
+  DevBuf<uint32_t> tq, tq_ctr;
+  DevBuf<double> srt;
   // cached pixel partition
   uint32_t part_key[6] = {0, 0, 0, 0, 0, 0};
   uint32_t npix = 0;
@@ -102,6 +107,7 @@ struct rptgpu_scene {
     ray.release(); hit.release(); rec.release(); shadow.release(); accum.release(); out_full.release();
     hit_obj.release(); draw.release(); queue_a.release(); queue_b.release(); counters.release();
     pixels.release(); nrec.release(); prec.release(); pcounters.release();
+    tq.release(); tq_ctr.release(); srt.release();
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -204,6 +210,12 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   h->queue_a.alloc(cap);
   h->queue_b.alloc(cap);
   h->counters.alloc(4);
+  if (h->has_deep) {
+    h->tq.alloc(cap);
+    h->tq_ctr.alloc(2);
+    h->srt.release();
+    h->srt.alloc((uint64_t)nl * cap);
+  }
   h->ws_cap = cap;
   h->ws_bounces = max_bounces;
 }
@@ -316,14 +328,30 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         const uint32_t* queue = nullptr; // identity at depth 0
         uint32_t* next = h->queue_a.p;
         for (uint32_t depth = 0; depth <= p->max_bounces && n_active; depth++) {
-          { Bracket b(h, RPT_K_EXTEND, prof); kt->extend(st, h->dscene, ps, queue, n_active); b.done(); }
+          const bool by_object = h->has_deep && !(p->flags & RPT_FLAG_GENERAL_TRAVERSAL);
+          const uint32_t trace_blocks = (uint32_t)std::max(1, h->num_cus * 4);
+          { Bracket b(h, RPT_K_EXTEND, prof);
+            if (by_object)
+              kt->query(st, h->dscene, ps, queue, n_active, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
+                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks);
+            else
+              kt->extend(st, h->dscene, ps, queue, n_active);
+            b.done(); }
           h->stats.extend_rays += n_active;
           HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(uint32_t), st));
           { Bracket b(h, RPT_K_SHADE, prof);
             kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, h->counters.p); b.done(); }
           if (any_lights) {
             Bracket b(h, RPT_K_SHADOW, prof);
-            kt->shadow(st, h->dscene, ps, queue, n_active, depth);
+            if (by_object) {
+              for (int l = 0; l < h->dscene.num_lights; l++)
+                if (h->light_casts[l])
+                  kt->query(st, h->dscene, ps, queue, n_active, l, h->srt.p, h->obj_deep.data(), h->obj_tris.data(),
+                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks);
+              kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
+            } else {
+              kt->shadow(st, h->dscene, ps, queue, n_active, depth);
+            }
             b.done();
           }
           uint32_t cnt[2] = {0, 0};
@@ -417,6 +445,15 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     h->num_cus = prop.multiProcessorCount;
     h->prefer_wavefront = fs.max_tree_depth >= 3;
+    for (int i = 0; i < fs.num_objects; i++) {
+      const rptdev::Inst& in = fs.insts[i];
+      bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
+      bool deep = tree && fs.tree_depth[in.tree] >= 8; // big enough to pay for compaction + its own launches
+      h->obj_deep.push_back(deep ? 1 : 0);
+      h->obj_tris.push_back(in.kind == RPT_SHAPE_MESH ? 1 : 0);
+      h->has_deep = h->has_deep || deep;
+    }
+    for (const rptdev::Light& l : fs.lights) h->light_casts.push_back(l.kind != RPT_LIGHT_AMBIENT ? 1 : 0);
     h->insts.upload(fs.insts, h->stream);
     h->trees.upload(fs.trees, h->stream);
     h->nodes.upload(fs.nodes, h->stream);

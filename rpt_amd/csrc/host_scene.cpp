@@ -222,6 +222,7 @@ struct Flattener {
     fs.nodes.insert(fs.nodes.end(), kb.nodes.begin(), kb.nodes.end());
     fs.refs.insert(fs.refs.end(), kb.refs.begin(), kb.refs.end());
     fs.trees.push_back(t);
+    fs.tree_depth.push_back(kb.max_depth);
     return (int)fs.trees.size() - 1;
   }
 

@@ -26,6 +26,7 @@ void kd_build(const std::vector<Box>& boxes, KdBuild& out);
 struct FlatScene {
   std::vector<rptdev::Inst> insts;
   std::vector<rptdev::Tree> trees;
+  std::vector<uint32_t> tree_depth; // per tree: depth of its deepest leaf
   std::vector<rptdev::KdNode> nodes;
   std::vector<uint32_t> refs;
   std::vector<rptdev::Tri> tris;

@@ -22,6 +22,13 @@ struct KernelTable {
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, uint32_t spp,
                 uint32_t nblocks);
+  // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run
+  // object by object with per-tree ray compaction and persistent traversal
+  void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
+                int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
+                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks);
+  void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
+                     uint32_t depth, const double* srt);
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)
