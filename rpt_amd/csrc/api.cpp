@@ -445,10 +445,12 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     h->num_cus = prop.multiProcessorCount;
     h->prefer_wavefront = fs.max_tree_depth >= 3;
+    uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
+    if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
     for (int i = 0; i < fs.num_objects; i++) {
       const rptdev::Inst& in = fs.insts[i];
       bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
-      bool deep = tree && fs.tree_depth[in.tree] >= 8; // big enough to pay for compaction + its own launches
+      bool deep = tree && fs.tree_depth[in.tree] >= deep_depth;
       h->obj_deep.push_back(deep ? 1 : 0);
       h->obj_tris.push_back(in.kind == RPT_SHAPE_MESH ? 1 : 0);
       h->has_deep = h->has_deep || deep;
