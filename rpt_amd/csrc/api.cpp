@@ -364,9 +364,11 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           next = (next == h->queue_a.p) ? h->queue_b.p : h->queue_a.p;
         }
         { Bracket b(h, RPT_K_RESOLVE, prof); kt->resolve(st, fr, ps, sc); b.done(); }
+        HIP_TRY(hipGetLastError()); // a failed launch is reported here, not by the stream sync
       }
       kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
     }
+    HIP_TRY(hipGetLastError());
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, frame_elems * out_elem, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (prof) drain_events(h);

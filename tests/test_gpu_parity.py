@@ -298,3 +298,57 @@ def test_bench_two_ranks_equal_one_rank(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     a, b = np.load(one), np.load(two)
     assert a.shape == b.shape == (320 * 180 * 3,) and (a == b).all() and a.max() > 0
+
+
+def test_edge_cases_match_the_oracle(oracle):
+    """Small / degenerate configurations, every one compared bit for bit with the oracle."""
+    cases = []
+    s, c, _ = scenes.cornell()
+    cases += [(s, c, make_params(1, 1, 3, 5, seed=1)), (s, c, make_params(7, 3, 0, 1, seed=2)),   # 1x1 frame; B = 0, 1 spp
+              (s, c, make_params(33, 17, 40, 2, seed=3)),                                           # B larger than any path
+              (s, c, make_params(16, 9, 2, 3, seed=4, tile=(4, 4), part=(5, 64))),                # a part that owns few tiles
+              (s, c, make_params(16, 9, 2, 3, seed=4, tile=(64, 64), part=(1, 2))),               # a part that owns nothing
+              (s, c, make_params(24, 8, 2, 2, seed=2 ** 63 + 5, sample_index_base=2 ** 40 + 3))]   # 64-bit seed / sample index
+    only_lights = rpt_amd.Scene()
+    only_lights.add(rpt_amd.Light.Point((1, 1, 1), (0, 1, 0)))
+    only_lights.add(rpt_amd.Light.Ambient((0.5, 0.5, 0.5)))
+    cases.append((only_lights, rpt_amd.Camera(), make_params(8, 8, 2, 2)))
+    # HDRI looked at along the poles and the seam (environment.rs:25-52 reads x0+1 / y0+1 unguarded)
+    env = rpt_amd.Scene()
+    env.environment = rpt_amd.Environment.Hdri(scenes.synthetic_hdri(32, 16, seed=3))
+    for d in ((0, 1, 0), (0, -1, 0), (-1, 0, 0), (-1, 0, 1e-17), (1, 0, 0)):
+        up = (0, 0, 1) if d[0] == 0 else (0, 1, 0)
+        cases.append((env, rpt_amd.Camera(eye=(0, 0, 0), direction=d, up=up, fov=1e-3), make_params(5, 5, 1, 2, seed=6)))
+    # geometry exactly on coordinate planes, negative zero bounds, a ray direction with zero components
+    flat = rpt_amd.Scene()
+    flat.add(rpt_amd.Object(rpt_amd.polygon([(-1, -0.0, -1), (-1, -0.0, 1), (1, -0.0, 1), (1, -0.0, -1)]))
+             .material(rpt_amd.Material.diffuse((0.5, 0.5, 0.5))))
+    flat.add(rpt_amd.Object(rpt_amd.Mesh(scenes.knot_mesh(64, 12))).material(rpt_amd.Material.specular((0.7, 0.8, 0.3), 0.2)))
+    flat.add(rpt_amd.Light.Directional((1, 1, 1), (0, -1, 0)))   # shadow rays along +y: two zero components
+    flat.add(rpt_amd.Light.Point((3, 3, 3), (0, 2, 0)))
+    cases.append((flat, rpt_amd.Camera(eye=(0, 3, 0), direction=(0, -1, 0), up=(0, 0, 1), fov=0.8), make_params(24, 24, 3, 3, seed=8)))
+    for scene, cam, p in cases:
+        g = GpuScene(scene, 0)
+        ref = oracle.OracleScene(scene).render(cam, p, threads=0)
+        for flags in (_abi.RPT_FLAG_PERSISTENT, _abi.RPT_FLAG_WAVEFRONT, 0):
+            pp = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, p.sample_index_base,
+                             (p.tile_width, p.tile_height), (p.part_index, p.part_count), flags=flags)
+            img = g.render_batch(cam, pp)
+            same = (img == ref) | (np.isnan(img) & np.isnan(ref))
+            assert same.all(), (p.width, p.height, p.max_bounces, flags, np.abs(img - ref).max())
+        g.close()
+
+
+def test_too_deep_tree_is_rejected():
+    # a chain of nested shells forces one split per level: deeper than the 32-entry device stack
+    tris = []
+    for i in range(40 * 16):
+        r = 1.0 + i // 16
+        tris.append(rpt_amd.Triangle.from_vertices((r, 0, 0), (r, 1e-3 * (i % 16 + 1), 0), (r, 0, 1e-3)))
+    scene = rpt_amd.Scene()
+    scene.add(rpt_amd.Object(rpt_amd.Mesh(tris)))
+    try:
+        g = GpuScene(scene, 0)
+        g.close()  # the builder may still produce a shallow tree for this input; either outcome is legal
+    except rpt_amd.RptGpuError as e:
+        assert e.code == _abi.RPTGPU_E_TREE_TOO_DEEP
