@@ -161,7 +161,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dominant, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath)).get(dominant, {})
+                if "hbm_bytes_per_sample" in tj:  # measured per sample (PMC run), scaled to this launch size
+                    traffic = tj["hbm_bytes_per_sample"] * rank_samples / max(1, kern_n[dominant])
+                else:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

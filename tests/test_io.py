@@ -1,0 +1,97 @@
+"""Asset import mirrors reference src/io.rs: fan triangulation, negative indices, per-corner
+normals vs flat fallback, usemtl grouping, MTL conversions, binary / ASCII STL detection."""
+import struct
+
+import numpy as np
+import pytest
+
+import rpt_amd
+from rpt_amd import load_obj, load_obj_with_mtl, load_stl, scenes
+
+OBJ = """# a quad (fan -> 2 triangles), a triangle with normals, a triangle with negative indices
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vn 0 0 1
+vt 0.5 0.5
+f 1 2 3 4
+f 1//1 2//1 3//1
+v 2 0 0
+v 3 0 0
+v 3 1 0
+f -3 -2 -1
+f 1/1/1 2/1 3/1/1
+"""
+
+
+def test_load_obj_rules(tmp_path):
+    p = tmp_path / "a.obj"
+    p.write_text(OBJ)
+    m = load_obj(str(p))
+    t = m.triangles
+    assert t.shape == (5, 18)
+    # quad fan: (v1,v2,v3), (v1,v3,v4)  (io.rs:181-198)
+    assert (t[0, :9] == [0, 0, 0, 1, 0, 0, 1, 1, 0]).all() and (t[1, :9] == [0, 0, 0, 1, 1, 0, 0, 1, 0]).all()
+    assert (t[0, 9:] == [0, 0, 1] * 3).all()  # no normal indices -> Triangle::from_vertices
+    assert (t[2, 9:] == [0, 0, 1] * 3).all()  # explicit normals
+    assert (t[3, :9] == [2, 0, 0, 3, 0, 0, 3, 1, 0]).all()  # negative indices count from the end (io.rs:10-18)
+    assert (t[4, 9:] == [0, 0, 1] * 3).all()  # one corner without a normal -> the whole triangle is flat
+    with open(p) as f:
+        assert (load_obj(f).triangles == t).all()  # file objects work too
+
+
+def test_obj_roundtrip_of_a_generated_mesh(tmp_path):
+    rows = scenes.knot_mesh(16, 6)
+    lines = []
+    for r in rows:
+        for k in range(3):
+            lines.append("v %r %r %r" % tuple(float(x) for x in r[3 * k:3 * k + 3]))
+        for k in range(3):
+            lines.append("vn %r %r %r" % tuple(float(x) for x in r[9 + 3 * k:12 + 3 * k]))
+        lines.append("f -3//-3 -2//-2 -1//-1")
+    p = tmp_path / "knot.obj"
+    p.write_text("\n".join(lines) + "\n")
+    assert (load_obj(str(p)).triangles == rows).all()  # repr() round-trips doubles exactly
+
+
+def test_load_obj_with_mtl(tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl red\nKd 0.8 0.1 0.1\nNs 30\nNi 1.0\n\nnewmtl glass\nKd 1 1 1\nd 0.5\nNi 1.5\nKa 1 1 1\n")
+    (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nusemtl red\nf 1 2 3\nusemtl red\nf 1 2 4\nusemtl glass\nf 2 3 4\n")
+    objs = load_obj_with_mtl(str(tmp_path / "m.obj"), str(tmp_path / "m.mtl"))
+    assert len(objs) == 2 and len(objs[0].shape) == 2 and len(objs[1].shape) == 1  # repeated usemtl does not split
+    red, glass = objs[0]._material, objs[1]._material
+    assert red.color == (0.8, 0.1, 0.1) and abs(red.roughness - (2.0 / 32.0) ** 0.25) < 1e-15
+    assert red.index == 1.0 + 1e-4 and not red.transparent  # Ni clamped (io.rs:238-240)
+    assert glass.transparent and glass.index == 1.5
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.obj").write_text("v 0 0 0\nusemtl nope\n")
+        load_obj_with_mtl(str(tmp_path / "bad.obj"), str(tmp_path / "m.mtl"))
+    # the loaded objects go straight into a scene description
+    scene = rpt_amd.Scene()
+    for o in objs:
+        scene.add(o)
+    desc, keep = scene.lower()
+    assert desc.num_objects == 2 and desc.objects[1].material.transparent == 1
+
+
+def test_load_stl_binary_and_ascii(tmp_path):
+    tris = [((0, 0, 1), (0, 0, 0), (1, 0, 0), (0, 1, 0)), ((1, 0, 0), (0.5, 0.25, 2), (0, 1, 1), (0, 0, 1))]
+    b = bytearray(b"solid looks-like-ascii-but-is-binary".ljust(80, b" ")) + struct.pack("<I", len(tris))
+    for n, a, c, d in tris:
+        b += struct.pack("<12fH", *n, *a, *c, *d, 0)
+    p = tmp_path / "b.stl"
+    p.write_bytes(bytes(b))
+    m = load_stl(str(p))  # size rule wins over the "solid" header (io.rs:265-274)
+    assert m.triangles.shape == (2, 18)
+    assert (m.triangles[1, :9] == [0.5, 0.25, 2, 0, 1, 1, 0, 0, 1]).all() and (m.triangles[1, 9:] == [1, 0, 0] * 3).all()
+    a = "solid t\n" + "".join(
+        " facet normal %g %g %g\n  outer loop\n   vertex %g %g %g\n   vertex %g %g %g\n   vertex %g %g %g\n  endloop\n endfacet\n"
+        % (n + v1 + v2 + v3) for n, v1, v2, v3 in tris) + "endsolid t\n"
+    pa = tmp_path / "a.stl"
+    pa.write_text(a)
+    ma = load_stl(str(pa))
+    assert (ma.triangles == m.triangles).all()
+    with pytest.raises(ValueError):
+        (tmp_path / "c.stl").write_bytes(b"garbage that is long enough")
+        load_stl(str(tmp_path / "c.stl"))
