@@ -280,6 +280,25 @@ void rptgpu_kdtree_free(RptKdTree* tree);
 int rptgpu_eval_math(rptgpu_scene* h, int fn, uint64_t n, const double* x, const double* y,
                      double* out);
 
+/* ---- device-resident Buffer (reference src/buffer.rs): SURVEY §8f rank 1.
+ * Keeps every batch of Renderer::sample on the GPU so that iterative_render (renderer.rs:103-115)
+ * needs no host round trip per batch; image() and variance() follow buffer.rs:43-93 exactly:
+ * per-pixel batch means summed in insertion order, box filter over (2r+1)^2 neighbours visited
+ * x-outer / y-inner, gamma 2.2 + clamp + truncation to u8 (color.rs:18-24). */
+typedef struct rptgpu_buffer rptgpu_buffer; /* opaque; belongs to the scene handle it was made from */
+int rptgpu_buffer_create(rptgpu_scene* h, uint32_t width, uint32_t height, uint32_t filter_radius,
+                         rptgpu_buffer** out);
+void rptgpu_buffer_destroy(rptgpu_buffer* b);
+/* Renderer::sample(iterations, &mut buffer): render one batch (params->width/height must match the
+ * buffer) and Buffer::add_samples it (buffer.rs:32-40), all on the device. */
+int rptgpu_buffer_sample(rptgpu_buffer* b, const RptCamera* camera, const RptRenderParams* params);
+/* Buffer::image (buffer.rs:43-56): out_rgb8 = height*width*3 bytes (host). */
+int rptgpu_buffer_image(rptgpu_buffer* b, uint8_t* out_rgb8);
+/* Buffer::variance (buffer.rs:59-73): mean over pixels of the per-pixel sample variance of the batch means. */
+int rptgpu_buffer_variance(rptgpu_buffer* b, double* out_variance);
+/* number of add_samples calls so far */
+int rptgpu_buffer_num_batches(const rptgpu_buffer* b, uint32_t* out);
+
 /* ---- accounting ---- */
 int rptgpu_get_stats(const rptgpu_scene* h, RptStats* out);
 int rptgpu_reset_stats(rptgpu_scene* h);

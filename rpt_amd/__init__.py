@@ -11,7 +11,7 @@ from ._abi import RptGpuError  # noqa: F401
 from .buffer import Buffer, Filter  # noqa: F401
 from .camera import Camera  # noqa: F401
 from .color import color_bytes, hex_color  # noqa: F401
-from .device import GpuScene, device_count, make_params  # noqa: F401
+from .device import DeviceBuffer, GpuScene, device_count, make_params  # noqa: F401
 from .environment import Environment, Hdri  # noqa: F401
 from .io import load_mtl, load_obj, load_obj_with_mtl, load_stl  # noqa: F401
 from .light import Light  # noqa: F401

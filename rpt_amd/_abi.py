@@ -126,6 +126,12 @@ SYMBOLS = [
     ("rptgpu_eval_math", C.c_int, [_VP, C.c_int, C.c_uint64, _PD, _PD, _PD]),
     ("rptgpu_kdtree_build", C.c_int, [_PD, C.c_uint64, C.POINTER(RptKdTree)]),
     ("rptgpu_kdtree_free", None, [C.POINTER(RptKdTree)]),
+    ("rptgpu_buffer_create", C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    ("rptgpu_buffer_destroy", None, [_VP]),
+    ("rptgpu_buffer_sample", C.c_int, [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams)]),
+    ("rptgpu_buffer_image", C.c_int, [_VP, C.POINTER(C.c_uint8)]),
+    ("rptgpu_buffer_variance", C.c_int, [_VP, _PD]),
+    ("rptgpu_buffer_num_batches", C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     ("rptgpu_get_stats", C.c_int, [_VP, C.POINTER(RptStats)]),
     ("rptgpu_reset_stats", C.c_int, [_VP]),
     ("rptgpu_kernel_name", C.c_char_p, [C.c_int]),

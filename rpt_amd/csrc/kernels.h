@@ -29,6 +29,12 @@ struct KernelTable {
                 uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);
+  // device-resident Buffer (buffer.rs)
+  void (*buffer_add)(hipStream_t, double* total, const double* batch, uint64_t n);
+  void (*buffer_image)(hipStream_t, const double* total, uint32_t w, uint32_t h, uint32_t radius, uint32_t nb,
+                       const double* thr, uint8_t* out);
+  void (*buffer_variance)(hipStream_t, const double* total, const double* const* batches, uint32_t nb, uint64_t npix,
+                          double* out);
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)

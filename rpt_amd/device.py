@@ -122,3 +122,48 @@ def kdtree_build(boxes, lib=None, prefix="rptgpu"):
     }
     free(C.byref(t))
     return out
+
+
+class DeviceBuffer:
+    """`Buffer` (reference src/buffer.rs) kept on the GPU: `rptgpu_buffer_*` of include/rpt_gpu.h.
+    Same results as the host `rpt_amd.Buffer`, without moving any batch to the host."""
+
+    def __init__(self, gpu_scene, width, height, filter=None):
+        self.gpu = gpu_scene
+        self.width, self.height = int(width), int(height)
+        radius = filter.radius if filter is not None else 0
+        h = C.c_void_p()
+        _abi.check(gpu_scene.lib.rptgpu_buffer_create(gpu_scene.handle, self.width, self.height, int(radius), C.byref(h)),
+                   gpu_scene.handle)
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.gpu.lib.rptgpu_buffer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sample(self, camera, params):
+        """Renderer::sample + Buffer::add_samples on the device."""
+        cam = camera.lower() if hasattr(camera, "lower") else camera
+        _abi.check(self.gpu.lib.rptgpu_buffer_sample(self.handle, C.byref(cam), C.byref(params)), self.gpu.handle)
+
+    def image(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        _abi.check(self.gpu.lib.rptgpu_buffer_image(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint8))), self.gpu.handle)
+        return out
+
+    def variance(self):
+        v = C.c_double(0.0)
+        _abi.check(self.gpu.lib.rptgpu_buffer_variance(self.handle, C.byref(v)), self.gpu.handle)
+        return v.value
+
+    def num_batches(self):
+        n = C.c_uint32(0)
+        _abi.check(self.gpu.lib.rptgpu_buffer_num_batches(self.handle, C.byref(n)), self.gpu.handle)
+        return n.value

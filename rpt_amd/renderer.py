@@ -5,7 +5,7 @@ import math
 
 from . import _abi
 from .buffer import Buffer, Filter
-from .device import GpuScene, make_params
+from .device import DeviceBuffer, GpuScene, make_params
 
 
 class Renderer:
@@ -72,7 +72,23 @@ class Renderer:
         self.sample(self._num_samples, buffer)
         return buffer.image()
 
-    def iterative_render(self, callback_interval, callback):  # renderer.rs:103-115
+    def iterative_render(self, callback_interval, callback, on_device=False):  # renderer.rs:103-115
+        """`on_device=True` keeps the Buffer on the GPU (rptgpu_buffer_*): the callback receives a
+        DeviceBuffer with the same image() / variance() and no batch ever travels to the host."""
+        if on_device:
+            buffer = DeviceBuffer(self.gpu_scene(), self._width, self._height, self._filter)
+            iteration = 0
+            self._samples_done = 0
+            while iteration < self._num_samples:
+                steps = min(self._num_samples - iteration, int(callback_interval))
+                params = make_params(self._width, self._height, self._max_bounces, steps, self._exposure_value,
+                                     self._seed, self._samples_done, precision=self._precision)
+                buffer.sample(self.camera, params)
+                self._samples_done += steps
+                iteration += steps
+                callback(iteration, buffer)
+            buffer.close()
+            return
         buffer = Buffer(self._width, self._height, self._filter)
         iteration = 0
         self._samples_done = 0

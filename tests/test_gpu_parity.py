@@ -352,3 +352,44 @@ def test_too_deep_tree_is_rejected():
         g.close()  # the builder may still produce a shallow tree for this input; either outcome is legal
     except rpt_amd.RptGpuError as e:
         assert e.code == _abi.RPTGPU_E_TREE_TOO_DEEP
+
+
+def test_device_buffer_equals_host_buffer(oracle):
+    """rptgpu_buffer_* (SURVEY §8f rank 1): image() and variance() of the device-resident Buffer equal
+    the host Buffer fed with the same batches — and the oracle's Buffer restatement — exactly."""
+    scene, cam, _ = scenes.cornell()
+    g = GpuScene(scene, 0)
+    W, H = 80, 45
+    for radius in (0, 1, 2):
+        dev = rpt_amd.DeviceBuffer(g, W, H, rpt_amd.Filter.Box(radius))
+        host = rpt_amd.Buffer(W, H, rpt_amd.Filter.Box(radius))
+        batches = []
+        for i in range(4):
+            p = make_params(W, H, 3, 2, seed=12, sample_index_base=2 * i, exposure_value=1.0)
+            dev.sample(cam, p)
+            b = g.render_batch(cam, p)
+            host.add_samples(b)
+            batches.append(b)
+        assert dev.num_batches() == 4
+        img = dev.image()
+        assert (img == host.image()).all()
+        assert (img == oracle.buffer_image(W, H, radius, batches)).all()
+        assert img.max() == 255 and img.min() < 40  # exposure +1 saturates the lit wall, corners stay dark
+        assert dev.variance() == oracle.buffer_variance(W, H, batches)
+        assert abs(dev.variance() - host.variance()) <= 1e-15 * abs(host.variance())
+        dev.close()
+    with pytest.raises(rpt_amd.RptGpuError):  # "Invalid sample dimension" (buffer.rs:33-36)
+        dev = rpt_amd.DeviceBuffer(g, W, H)
+        dev.sample(cam, make_params(W + 1, H, 1, 1))
+    with pytest.raises(rpt_amd.RptGpuError):  # "Pixel found with no samples" (buffer.rs:89)
+        rpt_amd.DeviceBuffer(g, W, H).image()
+    # iterative_render(on_device=True) == iterative_render on the host
+    r = rpt_amd.Renderer(scene, cam).width(W).height(H).max_bounces(2).num_samples(6).seed(3).filter(rpt_amd.Filter.Box(1))
+    a, bimgs = [], []
+    r.iterative_render(2, lambda it, buf: a.append((it, buf.variance(), buf.image())))
+    r.iterative_render(2, lambda it, buf: bimgs.append((it, buf.variance(), buf.image())), on_device=True)
+    assert [x[0] for x in a] == [x[0] for x in bimgs] == [2, 4, 6]
+    for x, y in zip(a, bimgs):
+        assert (x[2] == y[2]).all()
+        assert (np.isnan(x[1]) and np.isnan(y[1])) or abs(x[1] - y[1]) <= 1e-15 * abs(x[1])
+    g.close()
