@@ -11,7 +11,11 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --spp $SPP --no-cpu-baseline $EXTRA"
+# pass 1: the bench command itself.  With no extra args this is the DEFAULT bench line
+# (`python bench.py`: C2 at 512 spp, 3 steps + 1 warmup), so the kernel's average duration in the
+# stats equals the one bench.py reports; SPP > 0 profiles a shorter variant instead.
+if [ "$SPP" = "0" ]; then CMD="python $REPO/bench.py $EXTRA"; else CMD="python $REPO/bench.py --steps 2 --warmup 1 --spp $SPP --no-cpu-baseline $EXTRA"; fi
+echo "$CMD" > $OUT/trace_command.txt
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
 PCMD="python $REPO/bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline $EXTRA"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- $PCMD > $OUT/pmc_fetch.log 2>&1

@@ -90,8 +90,23 @@ json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1
 
 with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
     f.write("# rocprofv3 summary %s\n\n" % tag)
-    f.write("Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --spp 32 --no-cpu-baseline` "
-            "(scripts/profile.sh); PMC passes: `--pmc <counters> --kernel-trace -- python bench.py --steps 1 --warmup 0 --spp 4`.\n\n")
+    cmdf = os.path.join(src, "trace_command.txt")
+    cmd = open(cmdf).read().strip().replace(ROOT + "/", "").replace("/root/repo/", "") if os.path.exists(cmdf) else "python bench.py --steps 2 --warmup 1 --spp 32 --no-cpu-baseline"
+    cmd = " ".join(w.split("/")[-1] if w.endswith("bench.py") else w for w in cmd.split())
+    f.write("Command: `rocprofv3 --kernel-trace --stats -- %s` (scripts/profile.sh); PMC passes: "
+            "`--pmc <counters> --kernel-trace -- python bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline`.\n\n" % cmd)
+    bl = os.path.join(src, "bench_trace.log")
+    if os.path.exists(bl):
+        for line in open(bl):
+            if line.startswith("{") and '"ms_per_step"' in line:
+                try:
+                    d = json.loads(line)
+                    k = d["roofline"]["kernel"]
+                    f.write("bench.py's own line from that run: value = %.1f %s, ms_per_step = %.1f, `%s` avg launch = %.3f ms "
+                            "(HIP events) — compare with the avg us column below.\n\n"
+                            % (d["value"], d["unit"], d["ms_per_step"], k, d["roofline"]["kernels"][k]["avg_ms"]))
+                except Exception:
+                    pass
     f.write("| kernel | calls | total ms | avg us | % | VGPR | SGPR | scratch B/lane |\n|---|---|---|---|---|---|---|---|\n")
     for s, n, calls, tot, avg, pct in rows:
         v = regs.get(s, ("", "", ""))
