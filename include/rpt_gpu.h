@@ -159,7 +159,7 @@ enum {
   RPT_FLAG_WAVEFRONT = 2u,       /* force the multi-kernel wavefront pipeline (raygen / extend / shade /
                                     shadow / resolve; path state in HBM, lean 4-waves/SIMD traversal
                                     kernels with LDS stacks) */
-  RPT_FLAG_PERSISTENT = 8u       /* force the persistent per-pixel kernel (whole path in registers).
+  RPT_FLAG_PERSISTENT = 8u       /* force the persistent path kernel (whole path in registers).
                                     With neither flag the library picks: wavefront when the scene has
                                     real kd-trees (depth >= 3: traversal latency dominates and wants
                                     occupancy), persistent otherwise.  Both give the same bits. */
@@ -198,7 +198,7 @@ enum {
   RPT_K_SHADE = 2,  /* emission, NEE generation, BSDF sampling   */
   RPT_K_SHADOW = 3, /* shadow-ray traversal                      */
   RPT_K_RESOLVE = 4,/* nested firefly-clamp fold + accumulation  */
-  RPT_K_PATHS = 5,  /* persistent per-pixel kernel: all of the above in registers */
+  RPT_K_PATHS = 5,  /* persistent path kernel: all of the above in registers */
   RPT_K_COUNT = 8
 };
 

@@ -80,6 +80,9 @@ struct rptgpu_scene {
   uint64_t ws_cap = 0;
   uint32_t ws_bounces = 0;
   DevBuf<double> prec;                 // persistent kernel: depth records [bounces*8][threads]
+  DevBuf<double> lbuf;                 // persistent kernel: radiance of every sample of a launch [spp][3][npix]
+  uint64_t lbuf_max_bytes = 32ull << 30; // cap on lbuf (RPTGPU_LBUF_BYTES); larger batches run as several launches
+  uint32_t paths_chunk = 16;           // samples per work item (RPTGPU_PATHS_CHUNK)
   DevBuf<unsigned long long> pcounters; // [0] closest-hit rays [1] shadow rays
   int num_cus = 0;
   bool prefer_wavefront = false; // scene has real kd-trees: traversal-latency bound
@@ -272,23 +275,46 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     if (npix && !wavefront) {
       // ---- default pipeline: one persistent kernel, the whole path in registers
       h->accum.alloc((uint64_t)npix * 3);
+      // a batch runs as n_launch launches of spp_l samples each, sized so one launch's per-sample radiance
+      // buffer (24 B per sample) stays under lbuf_max_bytes: 512 spp at 1080p = 25.5 GB = one launch
+      uint64_t lbuf_budget = h->lbuf_max_bytes;
+      if (h->lbuf.n * sizeof(double) < lbuf_budget) { // growing: leave half of what is free to everyone else
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+          lbuf_budget = std::min<uint64_t>(lbuf_budget, std::max<uint64_t>(h->lbuf.n * sizeof(double), free_b / 2));
+      }
+      uint64_t spp_max = std::max<uint64_t>(1, lbuf_budget / ((uint64_t)npix * 3 * sizeof(double)));
+      uint32_t n_launch = (uint32_t)(((uint64_t)p->iterations + spp_max - 1) / spp_max);
+      uint32_t spp_l = n_launch ? (p->iterations + n_launch - 1) / n_launch : 0;
+      uint32_t chunk = std::max(1u, std::min(h->paths_chunk, std::max(1u, spp_l)));
+      uint64_t n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
+      if (n_items > 0xFFFFFFF0ull) { // 32-bit work counter
+        chunk = (uint32_t)(((uint64_t)spp_l * npix + 0xFFFFFFF0ull - 1) / 0xFFFFFFF0ull);
+        n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
+      }
       int per_cu = kt->paths_max_blocks_per_cu();
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
-      nblocks = (uint32_t)std::min<uint64_t>(nblocks, ((uint64_t)npix + 63) / 64);
+      nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
       uint64_t nthreads = (uint64_t)nblocks * 64;
       h->prec.alloc(std::max<uint64_t>(1, (uint64_t)p->max_bounces) * rptdev::REC_FIELDS * nthreads);
+      h->lbuf.alloc(std::max<uint64_t>(1, (uint64_t)spp_l * 3 * npix));
       h->counters.alloc(4);
       h->pcounters.alloc(16);
-      HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
       HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
       rptdev::Frame fr{};
       fr.width = p->width; fr.height = p->height; fr.npix = npix; fr.pixels = h->pixels.p;
       fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
-      fr.sample_base = p->sample_index_base;
       rptdev::Camera cam = make_camera(*camera);
-      { Bracket b(h, RPT_K_PATHS, prof);
-        kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, p->iterations, nblocks);
-        b.done(); }
+      if (p->iterations == 0) HIP_TRY(hipMemsetAsync(h->accum.p, 0, (uint64_t)npix * 3 * sizeof(double), st));
+      for (uint32_t s0 = 0; s0 < p->iterations; s0 += spp_l) {
+        uint32_t spp = std::min(spp_l, p->iterations - s0);
+        fr.sample_base = p->sample_index_base + s0;
+        HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
+        { Bracket b(h, RPT_K_PATHS, prof);
+          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks);
+          b.done(); }
+        kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
+      }
       HIP_TRY(hipGetLastError());
       kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
       unsigned long long rc[16] = {0};
@@ -475,6 +501,11 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     d.env_width = fs.env_width; d.env_height = fs.env_height; d.env_kind = fs.env_kind;
     d.num_objects = fs.num_objects; d.num_lights = (int32_t)fs.lights.size();
     d.num_shadow_lights = fs.num_shadow_lights;
+    if (const char* e = std::getenv("RPTGPU_LBUF_BYTES")) {
+      long long v = std::atoll(e);
+      if (v >= 24) h->lbuf_max_bytes = (uint64_t)v;
+    }
+    if (const char* e = std::getenv("RPTGPU_PATHS_CHUNK")) h->paths_chunk = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) {
       uint64_t v = std::strtoull(e, nullptr, 10);
       if (v >= 1024) h->target_paths = v;

@@ -20,8 +20,10 @@ struct KernelTable {
   // persistent per-pixel kernel: resident 64-thread blocks per CU, and the launch
   int (*paths_max_blocks_per_cu)();
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
-                uint32_t* work_counter, double* rec, unsigned long long* ray_counters, uint32_t spp,
-                uint32_t nblocks);
+                uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
+                uint32_t chunk, uint32_t nblocks);
+  // pixel sums of a launch's samples, in sample order
+  void (*sum_samples)(hipStream_t, const rptdev::Frame&, const double* lbuf, uint32_t spp, bool first);
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run
   // object by object with per-tree ray compaction and persistent traversal
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,

@@ -181,6 +181,26 @@ def test_small_workspace_chunks_give_the_same_image(built, monkeypatch):
     g2.close()
 
 
+def test_persistent_work_item_size_and_launch_split_do_not_change_the_image(built, monkeypatch):
+    # samples per work item and the split of a batch into launches (per-sample radiance buffer cap)
+    # are scheduling details: a pixel's samples are always summed in sample order
+    for name in ("cornell", "sphere"):
+        scene, cam, p, g = built(name)
+        pp = make_params(p.width, p.height, p.max_bounces, 7, p.exposure_value, p.seed, flags=_abi.RPT_FLAG_PERSISTENT)
+        ref = g.render_batch(cam, pp)
+        for chunk, spp_cap in ((1, 7), (3, 7), (16, 2), (2, 3), (5, 1)):
+            monkeypatch.setenv("RPTGPU_PATHS_CHUNK", str(chunk))
+            monkeypatch.setenv("RPTGPU_LBUF_BYTES", str(p.width * p.height * 24 * spp_cap))
+            g2 = GpuScene(scene, 0)
+            pq = make_params(p.width, p.height, p.max_bounces, 7, p.exposure_value, p.seed,
+                             flags=_abi.RPT_FLAG_PERSISTENT | _abi.RPT_FLAG_PROFILE_KERNELS)
+            img = g2.render_batch(cam, pq)
+            launches = g2.stats().kernel_launches[_abi.RPT_K_PATHS]
+            g2.close()
+            assert (img == ref).all(), (name, chunk, spp_cap)
+            assert launches == -(-7 // spp_cap), (launches, spp_cap)
+
+
 def test_fast_mode_is_statistically_equivalent(built):
     for name in ("cornell", "coverage"):
         scene, cam, p, g = built(name)
