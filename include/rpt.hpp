@@ -177,6 +177,7 @@ struct ShapeNode {
   int kind = RPT_SHAPE_SPHERE;
   Vec3 plane_normal;
   double plane_value = 0;
+  double monomial_height = 0, monomial_exp = 0;
   std::vector<RptTriangle> triangles;
   std::vector<Shape> children;
 };
@@ -222,6 +223,8 @@ class Shape { // value handle; Transformable (shape.rs:179-284): chained transfo
     }
     s.plane_normal[0] = node->plane_normal.x; s.plane_normal[1] = node->plane_normal.y; s.plane_normal[2] = node->plane_normal.z;
     s.plane_value = node->plane_value;
+    s.monomial_height = node->monomial_height;
+    s.monomial_exp = node->monomial_exp;
     if (node->kind == RPT_SHAPE_MESH) {
       s.triangles = node->triangles.data();
       s.num_triangles = node->triangles.size();
@@ -243,6 +246,12 @@ inline Shape plane(Vec3 normal, double value) {                  // shape.rs:297
   Shape s = make_shape(RPT_SHAPE_PLANE);
   s.node->plane_normal = normal;
   s.node->plane_value = value;
+  return s;
+}
+inline Shape monomial_surface(double height, double exp) {        // shape.rs:292-294
+  Shape s = make_shape(RPT_SHAPE_MONOMIAL);
+  s.node->monomial_height = height;
+  s.node->monomial_exp = exp;
   return s;
 }
 inline Shape Mesh(const std::vector<Triangle>& tris) { // Mesh = KdTree<Triangle>, mesh.rs:102

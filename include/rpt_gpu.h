@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPTGPU_ABI_VERSION 1
+#define RPTGPU_ABI_VERSION 2
 
 /* ---- error codes (replace the reference's panics: buffer.rs:26,33,89, plane.rs:35) ---- */
 enum {
@@ -75,8 +75,12 @@ enum {
   RPT_SHAPE_PLANE = 1,  /* src/shape/plane.rs:7-13  x . normal = value                        */
   RPT_SHAPE_CUBE = 2,   /* src/shape/cube.rs:8      unit cube [-0.5,0.5]^3                    */
   RPT_SHAPE_MESH = 3,   /* src/shape/mesh.rs:102    Mesh = KdTree<Triangle>                   */
-  RPT_SHAPE_GROUP = 4   /* KdTree<Box<dyn Bounded>> (examples/fractal_spheres.rs:45);
+  RPT_SHAPE_GROUP = 4,  /* KdTree<Box<dyn Bounded>> (examples/fractal_spheres.rs:45);
                            children must be SPHERE or CUBE, each optionally Transformed       */
+  RPT_SHAPE_MONOMIAL = 5 /* src/shape/monomial_surface.rs:12-18  y = height*(x^2+z^2)^(exp/2),
+                            x^2+z^2 <= 1; like the reference, intersection and normals are
+                            only valid for exp = 4 (monomial_surface.rs:10); top-level objects
+                            and Light::Object only                                            */
 };
 
 typedef struct RptShape {
@@ -85,6 +89,8 @@ typedef struct RptShape {
   RptTransform xf;
   double plane_normal[3]; /* PLANE: plane.rs:9  */
   double plane_value;     /* PLANE: plane.rs:12 */
+  double monomial_height; /* MONOMIAL: monomial_surface.rs:15 */
+  double monomial_exp;    /* MONOMIAL: monomial_surface.rs:17 (must be 4) */
   const RptTriangle* triangles; /* MESH: KdTree<Triangle>::objects (kdtree.rs:102)             */
   uint64_t num_triangles;
   const struct RptShape* children; /* GROUP: KdTree<Box<dyn Bounded>>::objects                 */

@@ -200,6 +200,8 @@ struct Rng {
     uint64_t p_int = (uint64_t)(p * 18446744073709551616.0);
     return next_u64() < p_int;
   }
+  // rand 0.8 Standard for bool: (next_u32() as i32) < 0; next_u32 here = low word of one u64 draw
+  bool gen_bool_std() { return (int32_t)(uint32_t)next_u64() < 0; }
   // rand 0.8 UniformInt::<usize>::sample for Uniform::from(0..n): widening multiply + zone
   uint64_t gen_index(uint64_t n) {
     uint64_t range = n;
@@ -400,6 +402,95 @@ struct Cube : Shape { // cube.rs
     return {v, n, 1.0 / 6.0};
   }
   BBox bounding_box() const override { return {{-0.5, -0.5, -0.5}, {0.5, 0.5, 0.5}}; } // :10-17
+};
+
+struct Monomial : Shape { // monomial_surface.rs (exp = 4 only, :10)
+  double height = 1.0, exp = 4.0;
+  BBox bounding_box() const override { return {{-1.0, 0.0, -1.0}, {1.0, height, 1.0}}; } // :183-190
+  bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override { // :21-106
+    COUNT_GEO(n_monomial);
+    double b_min, b_max;
+    bounding_box().intersect(ray, b_min, b_max);
+    if (rmax(b_min, t_min) > rmin(b_max, rec.time)) return false;
+    const V3 o = ray.origin, d = ray.dir;
+    auto dist = [&](double t) { // :26-31 ; powi(2) = s * s
+      double x = o.x + t * d.x, y = o.y + t * d.y, z = o.z + t * d.z;
+      double s = x * x + z * z;
+      return y - height * (s * s);
+    };
+    double coef0 = o.x * o.x + o.z * o.z;
+    double coef1 = 2. * (o.x * d.x + o.z * d.z);
+    double coef2 = d.x * d.x + d.z * d.z;
+    auto deriv = [&](double t) { // :35-41 ; left-to-right as written
+      double dy = 2. * coef0 * coef1 + 2. * t * (coef1 * coef1 + 2. * coef0 * coef2)
+                  + 3. * (t * t) * 2. * coef1 * coef2 + 4. * (t * (t * t)) * coef2 * coef2;
+      return d.y - height * dy;
+    };
+    auto deriv2 = [&](double t) { // :42-47
+      double dy = 2. * (coef1 * coef1 + 2. * coef0 * coef2) + 3. * 2. * t * 2. * coef1 * coef2
+                  + 4. * 3. * (t * t) * coef2 * coef2;
+      return -height * dy;
+    };
+    double t_max;
+    bool maximize = dist(t_min) < 0.0;
+    if (maximize) { // Newton on the distance from inside/below, :50-67
+      double cur_x = (b_min + b_max) / 2.;
+      for (int i = 0; i < 10; i++) {
+        double f = dist(cur_x);
+        if (f > 0.) break;
+        double der = deriv(cur_x), der2 = deriv2(cur_x);
+        cur_x -= der / der2;
+      }
+      t_max = cur_x; // (:61-63 only prints a diagnostic)
+      if (t_max < t_min) return false;
+    } else {
+      t_max = 10000.;
+    }
+    if ((dist(t_min) < 0.0) == (dist(t_max) < 0.0)) return false;
+    double l = t_min, r = t_max;
+    for (int i = 0; i < 60; i++) { // :74-81
+      double m = (l + r) / 2.0;
+      if ((dist(m) >= 0.0) == maximize) r = m;
+      else l = m;
+    }
+    if (r > rec.time) return false;
+    V3 pos = ray.at(r);
+    if (pos.x * pos.x + pos.z * pos.z > 1.0) return false; // :86-89
+    rec.time = r;
+    double s = pos.x * pos.x + pos.z * pos.z;
+    rec.normal = normalize(v3(height * 4.0 * pos.x * s, -1.0, height * 4.0 * pos.z * s)); // :92-96
+    if (dot(rec.normal, ray.dir) > 0.0) rec.normal = -rec.normal; // two-sided, :99-101
+    return true;
+  }
+  Sample sample(V3, Rng& rng) const override { // :108-123
+    double x, z;
+    rng.unit_circle(x, z);
+    // (x*x + z*z).powf(exp / 2.) with exp = 4: pow(s, 2.0), restated as s * s (the correctly rounded
+    // square; a libm pow may differ from it by one ulp on rare arguments)
+    double s = x * x + z * z;
+    V3 pos = v3(x, height * (s * s), z);
+    V3 normal = normalize(v3(height * 4. * pos.x * (pos.x * pos.x + pos.z * pos.z), -1.,
+                             height * 4. * pos.z * (pos.x * pos.x + pos.z * pos.z)));
+    const double AREA = 6.3406654362;
+    if (rng.gen_bool_std()) normal = -normal;
+    return {pos, normal, 1. / (2. * AREA)};
+  }
+  V3 closest_point(V3 point, int steps) const { // :126-152 (steps = 100), :154-181 (steps = 10000)
+    if (length(point) < 1e-12) return point;
+    double px = std::hypot(point.x, point.z), py = point.y;
+    double best = 1e18, best_x = -1.;
+    for (int i = -steps; i <= steps; i++) {
+      double xf = (double)i / (double)steps;
+      double x4 = (xf * xf) * (xf * xf); // powi(4)
+      double dx = px - xf, dy = py - height * x4;
+      double dist2 = dx * dx + dy * dy;
+      if (dist2 < best) { best = dist2; best_x = xf; }
+    }
+    double n = std::sqrt(point.x * point.x + point.z * point.z);
+    double qx = best_x * (point.x / n), qz = best_x * (point.z / n);
+    double r2 = qx * qx + qz * qz;
+    return v3(qx, height * (r2 * r2), qz);
+  }
 };
 
 struct Triangle : Shape { // mesh.rs:8-22
@@ -638,6 +729,14 @@ std::unique_ptr<Shape> make_shape(const RptShape& d, int depth = 0) {
       p->normal = from(d.plane_normal);
       p->value = d.plane_value;
       inner = std::move(p);
+      break;
+    }
+    case RPT_SHAPE_MONOMIAL: {
+      if (d.monomial_exp != 4.0) return nullptr; // monomial_surface.rs:10
+      auto m = std::make_unique<Monomial>();
+      m->height = d.monomial_height;
+      m->exp = d.monomial_exp;
+      inner = std::move(m);
       break;
     }
     case RPT_SHAPE_MESH: {
@@ -1254,6 +1353,12 @@ int oracle_shape_sample(const RptShape* shape, const double* target, uint64_t se
   to(r.n, out7 + 3);
   out7[6] = r.p;
   return RPTGPU_OK;
+}
+
+void oracle_monomial_closest_point(double height, const double* point, int steps, double* out3) {
+  Monomial m;
+  m.height = height;
+  to(m.closest_point(from(point), steps), out3);
 }
 
 void oracle_bbox_intersect(const double* box6, const double* origin, const double* dir,

@@ -46,6 +46,7 @@ typedef struct OracleCounters {
    * the unsuffixed ones above count closest-hit rays from trace_ray only */
   uint64_t n_inst_sh, n_root_sh, n_inner_sh, n_leaf_sh, n_ref_sh, n_tri_sh, n_sphere_sh, n_plane_sh,
       n_cube_sh;
+  uint64_t n_monomial, n_monomial_sh; /* MonomialSurface::intersect calls (monomial_surface.rs:21) */
 } OracleCounters;
 
 typedef struct oracle_scene oracle_scene;
@@ -97,6 +98,11 @@ int oracle_shape_intersect(const RptShape* shape, const double* origin, const do
 /* Shape::sample (shape.rs:24): out = point xyz, normal xyz, pdf */
 int oracle_shape_sample(const RptShape* shape, const double* target, uint64_t seed,
                         uint32_t pixel, uint64_t sample, uint32_t* draw, double* out7);
+
+/* MonomialSurface::closest_point (monomial_surface.rs:126-152, steps = 100) and
+ * closest_point_precise (:154-181, steps = 10000) — not on the render path; here so that the
+ * reference's own unit test `monomial_closest_point_works` (:192-240) can be replayed. */
+void oracle_monomial_closest_point(double height, const double* point, int steps, double* out3);
 
 /* BoundingBox::intersect (kdtree.rs:54-68): box = pmin xyz, pmax xyz */
 void oracle_bbox_intersect(const double* box6, const double* origin, const double* dir,

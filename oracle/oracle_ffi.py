@@ -21,7 +21,7 @@ class OracleCounters(C.Structure):
     _names = ["samples", "segments", "closest_rays", "shadow_rays", "hits", "misses", "n_inst",
               "n_root", "n_inner", "n_leaf", "n_ref", "n_tri", "n_sphere", "n_plane", "n_cube",
               "rng_draws", "n_inst_sh", "n_root_sh", "n_inner_sh", "n_leaf_sh", "n_ref_sh", "n_tri_sh",
-              "n_sphere_sh", "n_plane_sh", "n_cube_sh"]
+              "n_sphere_sh", "n_plane_sh", "n_cube_sh", "n_monomial", "n_monomial_sh"]
     _fields_ = [(n, C.c_uint64) for n in _names]
 
     def as_dict(self):
@@ -174,6 +174,12 @@ def shape_sample(shape, target, seed=1, pixel=0, sample=0, draw=0):
     if rc != 0:
         raise _abi.RptGpuError(rc, "oracle_shape_sample")
     return out[:3].copy(), out[3:6].copy(), out[6], dr.value
+
+
+def monomial_closest_point(height, point, steps=100):
+    out = np.zeros(3)
+    lib().oracle_monomial_closest_point(C.c_double(height), _v3(point), C.c_int(steps), _dp(out))
+    return out
 
 
 def bbox_intersect(box6, origin, direction):

@@ -20,5 +20,5 @@ from .object import Object  # noqa: F401
 from .renderer import Renderer  # noqa: F401
 from .scene import Scene  # noqa: F401
 from . import scenes  # noqa: F401
-from .shape import (Cube, KdTree, Mesh, Plane, Shape, Sphere, Transformed, Triangle,  # noqa: F401
+from .shape import (Cube, KdTree, Mesh, MonomialSurface, Plane, Shape, Sphere, Transformed, Triangle,  # noqa: F401
                     cube, monomial_surface, plane, polygon, sphere)

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPTGPU_LIB") or os.path.join(HERE, "lib", "librptgpu.so")  # RPTGPU_LIB: dev A/B builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 RPTGPU_OK = 0
 RPTGPU_E_INVALID_ARGUMENT = -1
@@ -22,7 +22,7 @@ RPTGPU_E_OUT_OF_MEMORY = -5
 RPTGPU_E_TREE_TOO_DEEP = -6
 RPTGPU_E_UNIMPLEMENTED_SAMPLE = -7
 
-RPT_SHAPE_SPHERE, RPT_SHAPE_PLANE, RPT_SHAPE_CUBE, RPT_SHAPE_MESH, RPT_SHAPE_GROUP = range(5)
+RPT_SHAPE_SPHERE, RPT_SHAPE_PLANE, RPT_SHAPE_CUBE, RPT_SHAPE_MESH, RPT_SHAPE_GROUP, RPT_SHAPE_MONOMIAL = range(6)
 RPT_LIGHT_POINT, RPT_LIGHT_AMBIENT, RPT_LIGHT_DIRECTIONAL, RPT_LIGHT_OBJECT = range(4)
 RPT_ENV_COLOR, RPT_ENV_HDRI = range(2)
 RPT_PRECISION_F64_STRICT, RPT_PRECISION_F64_FAST = range(2)
@@ -57,6 +57,7 @@ class RptShape(C.Structure):
 
 RptShape._fields_ = [("kind", C.c_int32), ("transformed", C.c_int32), ("xf", RptTransform),
                      ("plane_normal", V3), ("plane_value", f64),
+                     ("monomial_height", f64), ("monomial_exp", f64),
                      ("triangles", C.POINTER(RptTriangle)), ("num_triangles", C.c_uint64),
                      ("children", C.POINTER(RptShape)), ("num_children", C.c_uint64)]
 

@@ -86,6 +86,7 @@ struct rptgpu_scene {
   DevBuf<unsigned long long> pcounters; // [0] closest-hit rays [1] shadow rays
   int num_cus = 0;
   bool prefer_wavefront = false; // scene has real kd-trees: traversal-latency bound
+  bool ext_shapes = false;       // scene has a shape only the *_ext kernel builds implement
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
   bool has_deep = false;
@@ -133,7 +134,10 @@ int hip_fail(rptgpu_scene* h, const HipError& e) {
   return fail(h, code, buf);
 }
 
-const KernelTable* table_for(uint32_t mode) {
+// ext: the scene contains a shape of the extended set (RPT_SHAPE_MONOMIAL), which only the *_ext builds
+// of the kernels know; everything else runs the base builds
+const KernelTable* table_for(uint32_t mode, bool ext = false) {
+  if (ext) return mode == RPT_PRECISION_F64_FAST ? &rpt_fast_ext::TABLE : &rpt_strict_ext::TABLE;
   return mode == RPT_PRECISION_F64_FAST ? &rpt_fast::TABLE : &rpt_strict::TABLE;
 }
 
@@ -255,7 +259,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
   try {
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    const KernelTable* kt = table_for(p->precision_mode);
+    const KernelTable* kt = table_for(p->precision_mode, h->ext_shapes);
     const bool prof = (p->flags & RPT_FLAG_PROFILE_KERNELS) != 0;
     ensure_partition(h, *p);
     const uint32_t npix = h->npix;
@@ -483,6 +487,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       h->obj_tris.push_back(in.kind == RPT_SHAPE_MESH ? 1 : 0);
       h->has_deep = h->has_deep || deep;
     }
+    for (const rptdev::Inst& in : fs.insts) h->ext_shapes = h->ext_shapes || in.kind == RPT_SHAPE_MONOMIAL;
     for (const rptdev::Light& l : fs.lights) h->light_casts.push_back(l.kind != RPT_LIGHT_AMBIENT ? 1 : 0);
     h->insts.upload(fs.insts, h->stream);
     h->trees.upload(fs.trees, h->stream);
@@ -547,7 +552,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
     d_o.alloc(3 * n); d_d.alloc(3 * n); d_t.alloc(n); d_n.alloc(3 * n); d_obj.alloc(n);
     HIP_TRY(hipMemcpyAsync(d_o.p, origins, 3 * n * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_d.p, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice, st));
-    table_for(precision_mode)->extend_rays(st, h->dscene, d_o.p, d_d.p, n, d_t.p, d_n.p, d_obj.p);
+    table_for(precision_mode, h->ext_shapes)->extend_rays(st, h->dscene, d_o.p, d_d.p, n, d_t.p, d_n.p, d_obj.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_t, d_t.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_normal, d_n.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -255,6 +255,17 @@ struct Flattener {
         in.plane[3] = s.plane_value;
         is_bounded = false;
         break;
+      case RPT_SHAPE_MONOMIAL:
+        if (nesting > 0) { err = "MonomialSurface inside KdTree<Box<dyn Bounded>> is not supported"; return RPTGPU_E_UNSUPPORTED_SHAPE; }
+        if (s.monomial_exp != 4.0) {
+          err = "MonomialSurface: intersection and normals are only defined for exp = 4 (monomial_surface.rs:10)";
+          return RPTGPU_E_UNSUPPORTED_SHAPE;
+        }
+        in.plane[0] = s.monomial_height;
+        in.plane[1] = s.monomial_exp;
+        local.lo[0] = -1.0; local.lo[1] = 0.0; local.lo[2] = -1.0; // monomial_surface.rs:183-190
+        local.hi[0] = 1.0; local.hi[1] = s.monomial_height; local.hi[2] = 1.0;
+        break;
       case RPT_SHAPE_MESH: {
         if (nesting > 0) {
           err = "a Mesh inside KdTree<Box<dyn Bounded>> is not supported yet (SURVEY §8f rank 4)";

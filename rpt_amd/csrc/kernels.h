@@ -41,3 +41,6 @@ struct KernelTable {
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)
 namespace rpt_fast { extern const KernelTable TABLE; }   // -ffp-contract=fast
+// the same with the extended shape set (RPT_SHAPE_MONOMIAL) compiled in
+namespace rpt_strict_ext { extern const KernelTable TABLE; }
+namespace rpt_fast_ext { extern const KernelTable TABLE; }

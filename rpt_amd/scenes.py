@@ -17,7 +17,7 @@ from .light import Light
 from .material import Material
 from .object import Object
 from .scene import Scene
-from .shape import KdTree, Mesh, cube, plane, polygon, sphere
+from .shape import KdTree, Mesh, cube, monomial_surface, plane, polygon, sphere
 
 
 # ----------------------------------------------------------------------------- C1
@@ -260,5 +260,73 @@ def wine_glass(hdri_size=(2048, 1024), segments=128):
     return scene, camera, dict(width=3840, height=2160, max_bounces=16, num_samples=4096)
 
 
+def _basic_objects(scene):
+    """The cube / two spheres / floor / lights shared by examples/basic.rs:9-41 and monomial_glass.rs:36-71."""
+    scene.add(Object(cube().rotate_y(math.pi / 6.0).scale((0.5, 0.3, 0.4)).translate((0.4, -0.8, 4.0)))
+              .material(Material.specular(hex_color(0xFF00FF), 0.5)))
+    scene.add(Object(sphere().scale((0.5, 0.5, 0.5)).translate((1.5, -0.5, 1.0)))
+              .material(Material.specular(hex_color(0x0000FF), 0.1)))
+    scene.add(Object(sphere().scale((0.5, 0.5, 0.5)).translate((-1.5, -0.5, 1.0)))
+              .material(Material.specular(hex_color(0x00FF00), 0.1)))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.specular(hex_color(0xAAAAAA), 0.5)))
+    scene.add(Light.Ambient((0.01, 0.01, 0.01)))
+    scene.add(Light.Point((100.0, 100.0, 100.0), (0.0, 5.0, 5.0)))
+
+
+def basic():
+    """examples/basic.rs:6-50 (default material sphere, point + ambient light, default renderer settings)."""
+    scene = Scene()
+    scene.add(Object(sphere()))
+    _basic_objects(scene)
+    return scene, Camera(), dict(width=800, height=600, max_bounces=0, num_samples=1)
+
+
+def monomial_glass(hdri_size=(2048, 1024)):
+    """examples/monomial_glass.rs:26-87 (a mirror-like MonomialSurface bowl under an HDRI)."""
+    scene = Scene()
+    scene.environment = Environment.Hdri(synthetic_hdri(*hdri_size))
+    scene.add(Object(monomial_surface(2.0, 4.0).translate((0.0, -1.0, 0.0)))
+              .material(Material.metallic_(hex_color(0xFFFFFF), 0.0001)))
+    _basic_objects(scene)
+    return scene, Camera(), dict(width=800, height=600, max_bounces=1, num_samples=100)
+
+
+def spheres():
+    """examples/spheres.rs:13-60 (depth of field over five glossy spheres; Z-up)."""
+    scene = Scene()
+    balls = [((0.5, 4.0, 1.0), 0xE78999), ((3.15, -0.7, 1.5), 0xE7A94D), ((0.1, -2.0, 0.6), 0xB3E7AA),
+             ((-1.7, -0.2, 1.1), 0x7CA3E7), ((1.2, 0.4, 0.5), 0xAAAAAA)]
+    scene.add(Object(plane((0.0, 0.0, 1.0), 0.0)).material(Material.diffuse(hex_color(0xE7E7E7))))
+    for pos, col in balls:
+        scene.add(Object(sphere().scale((pos[2], pos[2], pos[2])).translate(pos))
+                  .material(Material.specular(hex_color(col), 0.1)))
+    scene.add(Light.Object(Object(sphere().scale((2.0, 2.0, 2.0)).translate((1.2, -1.5, 8.0)))
+                           .material(Material.light(hex_color(0xFFFFFF), 8.0))))
+    camera = Camera.look_at((0.7166, -9.2992, 2.8803), (0.8673, 0.2095, 0.9557), (0.0, 0.0, 1.0), 0.6911) \
+        .focus((0.1, -2.0, 0.6), 0.15)
+    return scene, camera, dict(width=800, height=600, max_bounces=6, num_samples=1000)
+
+
+def compound():
+    """examples/compound.rs:19-60 (compound of five cubes, three sphere lamps)."""
+    scene = Scene()
+    magic_angle = math.acos((3.0 * math.sqrt(5.0) - 1.0) / 8.0)
+    c_central = cube()
+    c_green = c_central.rotate(-magic_angle, (1.0, 1.0, 1.0))
+    c_red = c_green.scale((-1.0, 1.0, 1.0))
+    c_blue = c_green.scale((1.0, -1.0, 1.0))
+    c_orange = c_red.scale((1.0, -1.0, 1.0))
+    for shape, col in ((c_central, 0xC144EB), (c_green, 0x45E542), (c_red, 0xF55142), (c_blue, 0x4275F5),
+                       (c_orange, 0xF5BF42)):
+        scene.add(Object(shape).material(Material.specular(hex_color(col), 0.4)))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -0.80902)).material(Material.diffuse(hex_color(0xFFFFFF))))
+    for x, y, z, r, e in ((-2.0, 3.5, 0.5, 0.5, 60.0), (0.0, 0.5, 5.0, 1.0, 2.0), (2.0, 1.0, -5.0, 0.6, 10.0)):
+        scene.add(Light.Object(Object(sphere().scale((r, r, r)).translate((x, y, z)))
+                               .material(Material.light((1.0, 1.0, 1.0), e))))
+    camera = Camera.look_at((-0.9, 1.2, 2.4), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), math.pi / 4)
+    return scene, camera, dict(width=1024, height=1024, max_bounces=5, num_samples=50)
+
+
 SCENES = {"sphere": sphere_scene, "cornell": cornell, "dragon": dragon,
-          "fractal_spheres": fractal_spheres, "glass": glass, "wine_glass": wine_glass}
+          "fractal_spheres": fractal_spheres, "glass": glass, "wine_glass": wine_glass,
+          "basic": basic, "monomial_glass": monomial_glass, "spheres": spheres, "compound": compound}

@@ -70,6 +70,47 @@ class Plane(Shape):  # src/shape/plane.rs:7-13
         s.plane_value = self.value
 
 
+class MonomialSurface(Shape):  # src/shape/monomial_surface.rs:12-18
+    """y = height * sqrt(x^2 + z^2)^exp over the unit disc; like the reference (monomial_surface.rs:10)
+    intersection and normals are only valid for exp = 4."""
+
+    def __init__(self, height, exp):
+        self.height = float(height)
+        self.exp = float(exp)
+
+    def _fill(self, s, keep):
+        s.kind = _abi.RPT_SHAPE_MONOMIAL
+        s.monomial_height = self.height
+        s.monomial_exp = self.exp
+
+    def closest_point(self, point, steps=100):
+        """monomial_surface.rs:126-152 (steps=100) / :154-181 `closest_point_precise` (steps=10000)."""
+        import math
+        x, y, z = (float(c) for c in point)
+        if math.sqrt((x * x + y * y) + z * z) < 1e-12:
+            return (x, y, z)
+        px, py = math.hypot(x, z), y
+        best, best_x = 1e18, -1.0
+        for i in range(-steps, steps + 1):
+            xf = i / float(steps)
+            x4 = (xf * xf) * (xf * xf)
+            dx, dy = px - xf, py - self.height * x4
+            d2 = dx * dx + dy * dy
+            if d2 < best:
+                best, best_x = d2, xf
+        n = math.sqrt(x * x + z * z)
+
+        def div(a, b):  # IEEE division: a point on the axis normalises to NaN, as in the reference
+            return a / b if b != 0.0 else (math.nan if a == 0.0 or a != a else math.copysign(math.inf, a))
+
+        qx, qz = best_x * div(x, n), best_x * div(z, n)
+        r2 = qx * qx + qz * qz
+        return (qx, self.height * (r2 * r2), qz)
+
+    def closest_point_precise(self, point):
+        return self.closest_point(point, steps=10000)
+
+
 class Triangle(Shape):  # src/shape/mesh.rs:8-22
     def __init__(self, v1, v2, v3, n1, n2, n3):
         self.v1, self.v2, self.v3 = glm.vec3(*v1), glm.vec3(*v2), glm.vec3(*v3)
@@ -186,6 +227,10 @@ def sphere():
     return Sphere()
 
 
+def monomial_surface(height, exp):  # shape.rs:292-294
+    return MonomialSurface(height, exp)
+
+
 def plane(normal, value):
     return Plane(normal, value)
 
@@ -197,8 +242,3 @@ def cube():
 def polygon(verts):  # shape.rs:307-313 (triangle fan)
     tris = [Triangle.from_vertices(verts[0], verts[i], verts[i + 1]) for i in range(1, len(verts) - 1)]
     return Mesh(tris)
-
-
-def monomial_surface(height, exp):  # shape.rs:292-294 — out of the device's closed set
-    raise _abi.RptGpuError(_abi.RPTGPU_E_UNSUPPORTED_SHAPE,
-                           "MonomialSurface is not in the device shape set (SURVEY §8f rank 4)")

@@ -7,7 +7,7 @@ import numpy as np
 
 import rpt_amd
 from rpt_amd import (Camera, Environment, KdTree, Light, Material, Mesh, Object, Scene, cube, hex_color,
-                     make_params, plane, polygon, scenes, sphere)
+                     make_params, monomial_surface, plane, polygon, scenes, sphere)
 
 
 def coverage():
@@ -42,6 +42,28 @@ def coverage():
     return scene, camera
 
 
+def monomial():
+    """MonomialSurface seen from above, from below (the Newton branch) and edge-on, as a glass bowl, a
+    mirror bowl and an area light (MonomialSurface::sample), with every light kind."""
+    scene = Scene()
+    scene.environment = Environment.Hdri(scenes.synthetic_hdri(64, 32, seed=9))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0x998877))))
+    scene.add(Object(monomial_surface(2.0, 4.0).translate((0.0, -1.0, 0.0)))
+              .material(Material.metallic_(hex_color(0xFFFFFF), 0.05)))
+    scene.add(Object(monomial_surface(1.0, 4.0).scale((0.8, 1.2, 0.8)).rotate_z(0.4).translate((-2.2, -0.4, 0.5)))
+              .material(Material.clear(1.5, 0.02)))
+    scene.add(Object(monomial_surface(0.5, 4.0).rotate_x(math.pi).translate((2.2, 1.2, 0.0)))
+              .material(Material.specular(hex_color(0x5577CC), 0.3)))
+    scene.add(Object(sphere().scale((0.3, 0.3, 0.3)).translate((0.0, -0.6, 0.0)))
+              .material(Material.diffuse(hex_color(0xCC4444))))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    scene.add(Light.Point((40.0, 40.0, 40.0), (0.0, 5.0, 5.0)))
+    scene.add(Light.Object(Object(monomial_surface(0.3, 4.0).rotate_x(math.pi).scale((0.7, 0.7, 0.7))
+                                  .translate((0.0, 3.5, 0.5))).material(Material.light((1.0, 0.95, 0.9), 30.0))))
+    camera = Camera.look_at((0.0, 2.6, 6.5), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.75)
+    return scene, camera
+
+
 def small(name):
     """-> (scene, camera, params) for the named small config."""
     if name == "sphere":
@@ -65,7 +87,23 @@ def small(name):
     if name == "coverage":
         s, c = coverage()
         return s, c, make_params(64, 36, 5, 4, seed=107, exposure_value=0.5)
+    if name == "monomial":
+        s, c = monomial()
+        return s, c, make_params(64, 36, 4, 4, seed=108)
+    if name == "monomial_glass":
+        s, c, d = scenes.monomial_glass(hdri_size=(128, 64))
+        return s, c, make_params(64, 48, 1, 4, seed=109)
+    if name == "basic":
+        s, c, d = scenes.basic()
+        return s, c, make_params(64, 48, 0, 1, seed=110)
+    if name == "spheres":
+        s, c, d = scenes.spheres()
+        return s, c, make_params(64, 48, 6, 4, seed=111)
+    if name == "compound":
+        s, c, d = scenes.compound()
+        return s, c, make_params(48, 48, 5, 4, seed=112)
     raise KeyError(name)
 
 
-NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage"]
+NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
+         "monomial", "monomial_glass", "basic", "spheres", "compound"]

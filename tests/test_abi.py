@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == {s[0] for s in _abi.SYMBOLS}
-    assert lib.rptgpu_abi_version() == 1
+    assert lib.rptgpu_abi_version() == 2
 
 
 def test_struct_sizes_match_header(tmp_path):
@@ -69,8 +69,16 @@ def test_unsupported_shapes_rejected_at_scene_create_without_gpu():
         rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
 
-    with pytest.raises(rpt_amd.RptGpuError):
-        rpt_amd.monomial_surface(1.0, 4.0)
+    scene = rpt_amd.Scene()  # MonomialSurface: only exp = 4 (monomial_surface.rs:10), not inside a KdTree group
+    scene.add(rpt_amd.Object(rpt_amd.monomial_surface(1.0, 3.0)))
+    with pytest.raises(rpt_amd.RptGpuError) as e:
+        rpt_amd.GpuScene(scene)
+    assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
+    scene = rpt_amd.Scene()
+    scene.add(rpt_amd.Object(rpt_amd.KdTree([rpt_amd.monomial_surface(1.0, 4.0), rpt_amd.sphere()])))
+    with pytest.raises(rpt_amd.RptGpuError) as e:
+        rpt_amd.GpuScene(scene)
+    assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
     with pytest.raises(rpt_amd.RptGpuError):
         rpt_amd.KdTree([rpt_amd.plane((0, 1, 0), 0.0), rpt_amd.sphere()]).lower([])
 
