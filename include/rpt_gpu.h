@@ -75,8 +75,10 @@ enum {
   RPT_SHAPE_PLANE = 1,  /* src/shape/plane.rs:7-13  x . normal = value                        */
   RPT_SHAPE_CUBE = 2,   /* src/shape/cube.rs:8      unit cube [-0.5,0.5]^3                    */
   RPT_SHAPE_MESH = 3,   /* src/shape/mesh.rs:102    Mesh = KdTree<Triangle>                   */
-  RPT_SHAPE_GROUP = 4,  /* KdTree<Box<dyn Bounded>> (examples/fractal_spheres.rs:45);
-                           children must be SPHERE or CUBE, each optionally Transformed       */
+  RPT_SHAPE_GROUP = 4,  /* KdTree<Box<dyn Bounded>> (examples/fractal_spheres.rs:45,
+                           fractal_teapots.rs:69); children must be SPHERE, CUBE or MESH, each
+                           optionally Transformed; MESH children that share one triangle array
+                           (Arc<Mesh>) share one tree on the device                           */
   RPT_SHAPE_MONOMIAL = 5 /* src/shape/monomial_surface.rs:12-18  y = height*(x^2+z^2)^(exp/2),
                             x^2+z^2 <= 1; like the reference, intersection and normals are
                             only valid for exp = 4 (monomial_surface.rs:10); top-level objects

@@ -487,6 +487,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       h->obj_tris.push_back(in.kind == RPT_SHAPE_MESH ? 1 : 0);
       h->has_deep = h->has_deep || deep;
     }
+    h->ext_shapes = fs.nested_mesh;
     for (const rptdev::Inst& in : fs.insts) h->ext_shapes = h->ext_shapes || in.kind == RPT_SHAPE_MONOMIAL;
     for (const rptdev::Light& l : fs.lights) h->light_casts.push_back(l.kind != RPT_LIGHT_AMBIENT ? 1 : 0);
     h->insts.upload(fs.insts, h->stream);

@@ -267,10 +267,7 @@ struct Flattener {
         local.hi[0] = 1.0; local.hi[1] = s.monomial_height; local.hi[2] = 1.0;
         break;
       case RPT_SHAPE_MESH: {
-        if (nesting > 0) {
-          err = "a Mesh inside KdTree<Box<dyn Bounded>> is not supported yet (SURVEY §8f rank 4)";
-          return RPTGPU_E_UNSUPPORTED_SHAPE;
-        }
+        if (nesting > 0) fs.nested_mesh = true; // kd-tree of kd-trees (examples/fractal_teapots.rs)
         if (!s.triangles && s.num_triangles) { err = "null triangles"; return RPTGPU_E_INVALID_ARGUMENT; }
         auto key = std::make_pair((const void*)s.triangles, (uint64_t)s.num_triangles);
         auto it = mesh_cache.find(key);
@@ -315,8 +312,8 @@ struct Flattener {
         std::vector<Box> boxes(s.num_children);
         for (uint64_t i = 0; i < s.num_children; i++) {
           const RptShape& c = s.children[i];
-          if (c.kind != RPT_SHAPE_SPHERE && c.kind != RPT_SHAPE_CUBE) {
-            err = "KdTree<Box<dyn Bounded>> children must be spheres or cubes (optionally Transformed)";
+          if (c.kind != RPT_SHAPE_SPHERE && c.kind != RPT_SHAPE_CUBE && c.kind != RPT_SHAPE_MESH) {
+            err = "KdTree<Box<dyn Bounded>> children must be spheres, cubes or meshes (optionally Transformed)";
             return RPTGPU_E_UNSUPPORTED_SHAPE;
           }
           bool b = true;

@@ -236,6 +236,50 @@ def fractal_spheres(levels=5):
 
 
 # ----------------------------------------------------------------------------- C5
+def _teapot_stand_in(nu, nv):
+    rows = knot_mesh(nu, nv, seed=0x7EA)
+    rows[:, :9] *= 3.0  # about the extent of teapot.obj (the example halves it again)
+    return rows
+
+
+def fractal_teapots(levels=5, mesh=None):
+    """examples/fractal_teapots.rs:13-87 — a kd-tree of kd-trees: every level is a
+    KdTree<Box<dyn Bounded>> whose children are Transformed<Arc<Mesh>> sharing ONE mesh.
+    `mesh` is a Mesh (e.g. load_obj("examples/teapot.obj")); the default is a seeded procedural
+    stand-in because the reference's asset is not redistributed here."""
+    if mesh is None:
+        mesh = Mesh(_teapot_stand_in(48, 8))
+    colors = [0x264653, 0x2A9D8F, 0xE9C46A, 0xF4A261, 0xE76F51][:levels]
+    groups = [[] for _ in colors]
+
+    def gen(p, rad, depth, last_dir):  # fractal_teapots.rs:13-46
+        groups[depth].append(mesh.scale((0.5, 0.5, 0.5)).scale((rad, rad, rad)).translate(p))
+        if depth == len(groups) - 1:
+            return
+        disp = rad * 7.0 / 5.0
+        dx = [disp, -disp, 0.0, 0.0, 0.0, 0.0]
+        dy = [0.0, 0.0, disp, -disp, 0.0, 0.0]
+        dz = [0.0, 0.0, 0.0, 0.0, disp, -disp]
+        for i in range(6):
+            if last_dir is None or i != (last_dir ^ 1):
+                gen((p[0] + dx[i], p[1] + dy[i], p[2] + dz[i]), rad * 2.0 / 5.0, depth + 1, i)
+
+    gen((0.0, 0.0, 0.0), 1.0, 0, None)
+    scene = Scene()
+    for i, group in enumerate(groups):
+        scene.add(Object(KdTree(group)).material(Material.specular(hex_color(colors[i]), 0.25)))
+    scene.add(Object(plane((0.0, 0.0, 1.0), -6.0)).material(Material.diffuse(hex_color(0xFFCCCC))))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    n = math.sqrt((0.0 * 0.0 + 0.65 * 0.65) + 1.0 * 1.0)
+    scene.add(Light.Directional((0.6, 0.6, 0.6), (0.0 / n, -0.65 / n, -1.0 / n)))
+    scene.add(Light.Point((100.0, 100.0, 100.0), (0.0, 5.0, 5.0)))
+    dn = math.sqrt((0.285714 * 0.285714 + 0.5 * 0.5) + 1.0 * 1.0)
+    un = math.sqrt((0.0 + 1.0) + 0.25)
+    camera = Camera(eye=(2.0, 3.5, 7.0), direction=(-0.285714 / dn, -0.5 / dn, -1.0 / dn),
+                    up=(0.0 / un, 1.0 / un, -0.5 / un), fov=math.pi / 6.0)
+    return scene, camera, dict(width=800, height=600, max_bounces=0, num_samples=1)
+
+
 def glass(hdri_size=(2048, 1024)):
     """examples/glass.rs:27-50 (metal + glass unit spheres under an HDRI)."""
     scene = Scene()
@@ -329,4 +373,4 @@ def compound():
 
 SCENES = {"sphere": sphere_scene, "cornell": cornell, "dragon": dragon,
           "fractal_spheres": fractal_spheres, "glass": glass, "wine_glass": wine_glass,
-          "basic": basic, "monomial_glass": monomial_glass, "spheres": spheres, "compound": compound}
+          "fractal_teapots": fractal_teapots, "basic": basic, "monomial_glass": monomial_glass, "spheres": spheres, "compound": compound}

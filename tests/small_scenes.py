@@ -102,8 +102,18 @@ def small(name):
     if name == "compound":
         s, c, d = scenes.compound()
         return s, c, make_params(48, 48, 5, 4, seed=112)
+    if name == "fractal_teapots":
+        m = Mesh(scenes._teapot_stand_in(24, 6))
+        s, c, d = scenes.fractal_teapots(levels=3, mesh=m)
+        # additions to the example: a lamp that is itself a kd-tree of kd-trees (KdTree::sample over a
+        # Mesh child), and bounces (the example renders with the Renderer defaults, 0 bounces) so that
+        # shadow and bounce rays go through the nested traversal too
+        s.add(Light.Object(Object(KdTree([m.scale((0.3, 0.3, 0.3)).translate((1.5, 2.5, 3.0)),
+                                          sphere().scale((0.2, 0.2, 0.2)).translate((2.2, 2.5, 3.0))]))
+                           .material(Material.light((1.0, 0.9, 0.8), 25.0))))
+        return s, c, make_params(64, 48, 3, 4, seed=113)
     raise KeyError(name)
 
 
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
-         "monomial", "monomial_glass", "basic", "spheres", "compound"]
+         "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots"]
