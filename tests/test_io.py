@@ -95,3 +95,44 @@ def test_load_stl_binary_and_ascii(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "c.stl").write_bytes(b"garbage that is long enough")
         load_stl(str(tmp_path / "c.stl"))
+
+
+# ---- the reference's own asset files, when the reference tree is present (this container only;
+# ---- the GPU box has no /root/reference, and these tests need no GPU)
+REF_EXAMPLES = "/root/reference/examples"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF_EXAMPLES), reason="reference tree not present")
+@pytest.mark.parametrize("name,kind", [("teapot.obj", "obj"), ("wine_glass.obj", "obj"), ("rustacean.obj", "obj"),
+                                       ("monomial.obj", "obj"), ("cylinder.stl", "stl")])
+def test_reference_assets_load_and_build(name, kind):
+    import os
+
+    from oracle import oracle_ffi as O
+    path = os.path.join(REF_EXAMPLES, name)
+    mesh = load_obj(path) if kind == "obj" else load_stl(path)
+    t = mesh.triangles
+    assert t.ndim == 2 and t.shape[1] == 18 and len(t) > 50
+    assert np.isfinite(t).all()
+    nrm = np.linalg.norm(t[:, 9:].reshape(-1, 3), axis=1)
+    assert (np.abs(nrm - 1.0) < 1e-3).mean() > 0.99  # 6-decimal file normals (passed through, io.rs:49-53) or from_vertices
+    # the face count of the file is the triangle count after fan triangulation (io.rs:181-198)
+    if kind == "obj":
+        fans = 0
+        with open(path) as f:
+            for line in f:
+                tok = line.split()
+                if tok and tok[0] == "f":
+                    fans += len(tok) - 3
+        assert fans == len(t)
+    # the product's kd builder and the restatement of KdTree::new agree on the real asset
+    lo = np.minimum(np.minimum(t[:, 0:3], t[:, 3:6]), t[:, 6:9])
+    hi = np.maximum(np.maximum(t[:, 0:3], t[:, 3:6]), t[:, 6:9])
+    boxes = np.concatenate([lo, hi], axis=1)
+    from rpt_amd import _abi
+    from rpt_amd.device import kdtree_build
+    a = kdtree_build(boxes, _abi.load_library(), "rptgpu")
+    b = kdtree_build(boxes, O.lib(), "oracle")
+    assert a["max_depth"] == b["max_depth"] and a["max_depth"] <= 32
+    for k in ("split", "info", "a", "b", "refs"):
+        assert a[k].shape == b[k].shape and (a[k] == b[k]).all(), k
