@@ -326,9 +326,10 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       HIP_TRY(hipStreamSynchronize(st));
       if (std::getenv("RPTGPU_PRINT_PHASES")) { // only meaningful with a -DRPT_PHASE_TIMERS build
         unsigned long long tot = 0;
-        for (int i = 2; i < 10; i++) tot += rc[i];
-        const char* nm[8] = {"fetch", "raygen", "closest_hit", "illuminate", "visible", "nee_bsdf", "sample_f", "bsdf+rec+fold"};
-        for (int i = 0; i < 8 && tot; i++) std::fprintf(stderr, "phase %-14s %6.2f %%\n", nm[i], 100.0 * rc[2 + i] / tot);
+        for (int i = 2; i < 14; i++) tot += rc[i];
+        const char* nm[12] = {"fetch", "raygen", "closest_hit", "illuminate", "visible", "nee_bsdf", "sample_f",
+                              "fold+store", "bsdf", "record", "rejoin", "-"};
+        for (int i = 0; i < 12 && tot; i++) std::fprintf(stderr, "phase %-14s %6.2f %%\n", nm[i], 100.0 * rc[2 + i] / tot);
       }
       h->stats.samples += (uint64_t)npix * p->iterations;
       h->stats.extend_rays += rc[0];

@@ -59,8 +59,11 @@ def test_device_math_is_bit_identical_to_host(oracle, built):
 
 
 def test_shared_reciprocal_division_is_ieee(built):
-    """The kernels divide through a shared refined reciprocal (kernels.inc `div_r`); it must be the
-    correctly rounded IEEE quotient, bit for bit — numpy's `/` is the reference."""
+    """Where several quotients share a denominator the kernels divide through a shared refined reciprocal
+    (kernels.inc `div_fast`, guarded by `RcpD::ok` and `safe_range`); wherever that guard holds the result
+    must be the correctly rounded IEEE quotient, bit for bit — numpy's `/` is the reference.  (In the
+    kernels the guard is evaluated per wave and the other side is the plain division, so the guard can
+    only select between two ways of computing the same bits.)"""
     g = built("sphere")[3]
     rs = np.random.RandomState(17)
     n = 1 << 22
