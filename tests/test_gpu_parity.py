@@ -361,7 +361,8 @@ def test_edge_cases_match_the_oracle(oracle):
               (s, c, make_params(33, 17, 40, 2, seed=3)),                                           # B larger than any path
               (s, c, make_params(16, 9, 2, 3, seed=4, tile=(4, 4), part=(5, 64))),                # a part that owns few tiles
               (s, c, make_params(16, 9, 2, 3, seed=4, tile=(64, 64), part=(1, 2))),               # a part that owns nothing
-              (s, c, make_params(24, 8, 2, 2, seed=2 ** 63 + 5, sample_index_base=2 ** 40 + 3))]   # 64-bit seed / sample index
+              (s, c, make_params(24, 8, 2, 2, seed=2 ** 63 + 5, sample_index_base=2 ** 40 + 3)),   # 64-bit seed / sample index
+              (s, c, make_params(12, 8, 2, 5, seed=7, sample_index_base=2 ** 32 - 2))]              # the batch crosses 2^32 samples
     only_lights = rpt_amd.Scene()
     only_lights.add(rpt_amd.Light.Point((1, 1, 1), (0, 1, 0)))
     only_lights.add(rpt_amd.Light.Ambient((0.5, 0.5, 0.5)))
