@@ -5,6 +5,13 @@
 
 #include "device_types.h"
 
+// buffers of the optional ray sort in front of a per-tree traversal (all sized for the query's n)
+struct SortBufs {
+  uint32_t *keys_in, *keys_out, *vals_in;
+  void* tmp;
+  size_t tmp_bytes;
+};
+
 struct KernelTable {
   void (*raygen)(hipStream_t, const rptdev::Frame&, const rptdev::Camera&, const rptdev::PathState&, uint32_t n_paths);
   void (*extend)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n);
@@ -28,7 +35,8 @@ struct KernelTable {
   // object by object with per-tree ray compaction and persistent traversal
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                 int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
-                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks);
+                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort);
+  size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);
   // device-resident Buffer (buffer.rs)

@@ -157,6 +157,21 @@ def test_render_bit_equal_to_golden(built, name, pipeline):
     assert (img == ref).all(), "max |delta| = %g on %d pixels" % (np.abs(img - ref).max(), (img != ref).any(axis=1).sum())
 
 
+@pytest.mark.parametrize("sort", ["0", "1"])
+@pytest.mark.parametrize("name", small_scenes.NAMES)
+def test_per_tree_queries_and_ray_sorting_do_not_change_the_image(name, sort, monkeypatch):
+    # every tree treated as "deep" (object-by-object queries with per-tree compaction and persistent
+    # traversal), with and without the ray sort in front of the traversal: scheduling only
+    monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "1")
+    monkeypatch.setenv("RPTGPU_SORT_RAYS", sort)
+    scene, cam, p = small_scenes.small(name)
+    g = GpuScene(scene, 0)
+    pw = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=_abi.RPT_FLAG_WAVEFRONT)
+    img = g.render_batch(cam, pw)
+    g.close()
+    assert (img == load(name)["image"]).all()
+
+
 def test_c1_full_config_bit_equal_to_oracle(oracle):
     # BASELINE configs[0]: examples/sphere.rs, 960x540, 2 bounces, 100 spp — in full
     scene, cam, cfg = scenes.sphere_scene()
