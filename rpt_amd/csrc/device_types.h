@@ -64,7 +64,9 @@ struct alignas(16) Tree {
   uint32_t num_prims;
   double bounds[6];   // p_min xyz, p_max xyz (kdtree.rs:103)
   uint32_t regular;   // 1: every split lies inside its cell -> the compact traversal is exact
-  uint32_t _pad[3];
+  uint32_t root_leaf; // 0, or 1 + the entry count when node 0 is a leaf (fewer than 16 primitives, kdtree.rs:236)
+  uint32_t root_first; // that leaf's first entry in refs[] / lrec[]
+  uint32_t _pad;
 };
 
 struct alignas(16) Material {

@@ -215,6 +215,10 @@ struct Flattener {
     t.prim_base = prim_base;
     t.num_prims = (uint32_t)boxes.size();
     t.regular = kb.regular ? 1u : 0u;
+    if (!kb.nodes.empty() && (kb.nodes[0].ib & 3u) == 3u) {
+      t.root_leaf = 1u + (kb.nodes[0].ib >> 2);
+      t.root_first = kb.nodes[0].a;
+    }
     Box bounds = empty_box(); // KdTree::new bounds fold kdtree.rs:110-113
     for (const Box& b : boxes) bounds = merge(bounds, b);
     for (int k = 0; k < 3; k++) { t.bounds[k] = bounds.lo[k]; t.bounds[3 + k] = bounds.hi[k]; }

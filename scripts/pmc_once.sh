@@ -6,10 +6,10 @@ OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT -o bench -- python $REPO/bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline $ARGS > $OUT/log.txt 2>&1
 python - <<PY
-import sqlite3
+import re, sqlite3
 c = sqlite3.connect("$OUT/bench_results.db")
 q = "select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name"
 for k, cn, tot, n in c.execute(q):
-    k = k.split("(")[0].split("::")[-1]
+    k = re.sub(r"\\b\\w+::", "", k.split("(")[0]).replace("void ", "").strip()
     if k.startswith("rpt_"): print("%-12s %-28s %.4g (%d launches)" % (k, cn, tot, n))
 PY

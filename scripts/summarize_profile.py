@@ -20,7 +20,15 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    return name.split("(")[0].split("::")[-1]
+    """'void rpt_strict::rpt_paths<rpt_strict::KdFlat>(rptdev::Scene, ...)' -> 'rpt_paths<KdFlat>';
+    the two builds of the persistent path kernel are reported under the bench line's name `rpt_paths`
+    (the variant is listed in the notes of profiles/README.md)."""
+    import re
+    head = name.split("(")[0]
+    head = re.sub(r"\b\w+::", "", head).replace("void ", "").strip()
+    if head.startswith("rpt_paths<"):
+        return "rpt_paths"
+    return head
 
 
 def db(sub):
