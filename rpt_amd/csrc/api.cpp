@@ -86,7 +86,9 @@ struct rptgpu_scene {
   DevBuf<unsigned long long> pcounters; // [0] closest-hit rays [1] shadow rays
   int num_cus = 0;
   bool prefer_wavefront = false; // scene has real kd-trees: traversal-latency bound
-  bool all_flat = false;         // every tree is a single leaf: the path kernel without any traversal code
+  bool all_flat = false;         // every tree is a single leaf (and the scene fits the LDS tables): the path kernel
+                                 // without any traversal code
+  uint32_t flat_refs = 0, flat_tris = 0;
   bool ext_shapes = false;       // scene has a shape only the *_ext kernel builds implement
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
@@ -329,7 +331,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         fr.sample_base = p->sample_index_base + s0;
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
         { Bracket b(h, RPT_K_PATHS, prof);
-          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks, h->all_flat && !h->dscene.force_general);
+          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks, h->all_flat && !h->dscene.force_general,
+                    h->flat_refs, h->flat_tris);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
       }
@@ -518,6 +521,9 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     }
     h->all_flat = true;
     for (const rptdev::Tree& tr : fs.trees) h->all_flat = h->all_flat && tr.root_leaf != 0;
+    h->all_flat = h->all_flat && fs.refs.size() <= 64 && fs.tris.size() <= 64 && fs.num_objects <= 32; // FLAT_MAX*, kernels.inc
+    h->flat_refs = (uint32_t)fs.refs.size();
+    h->flat_tris = (uint32_t)fs.tris.size();
     h->ext_shapes = fs.nested_mesh;
     for (const rptdev::Inst& in : fs.insts) h->ext_shapes = h->ext_shapes || in.kind == RPT_SHAPE_MONOMIAL;
     for (const rptdev::Light& l : fs.lights) h->light_casts.push_back(l.kind != RPT_LIGHT_AMBIENT ? 1 : 0);

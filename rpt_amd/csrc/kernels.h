@@ -28,7 +28,7 @@ struct KernelTable {
   int (*paths_max_blocks_per_cu)();
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
-                uint32_t chunk, uint32_t nblocks, bool flat);
+                uint32_t chunk, uint32_t nblocks, bool flat, uint32_t flat_refs, uint32_t flat_tris);
   // pixel sums of a launch's samples, in sample order
   void (*sum_samples)(hipStream_t, const rptdev::Frame&, const double* lbuf, uint32_t spp, bool first);
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run
