@@ -312,12 +312,16 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         chunk = (uint32_t)(((uint64_t)spp_l * npix + 0xFFFFFFF0ull - 1) / 0xFFFFFFF0ull);
         n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
       }
-      int per_cu = kt->paths_max_blocks_per_cu();
+      const bool flat = h->all_flat && !h->dscene.force_general;
+      int per_cu = kt->paths_max_blocks_per_cu(flat);
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
       nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
       uint64_t nthreads = (uint64_t)nblocks * 64;
       h->prec.alloc(std::max<uint64_t>(1, (uint64_t)p->max_bounces) * rptdev::REC_FIELDS * nthreads);
       h->lbuf.alloc(std::max<uint64_t>(1, (uint64_t)spp_l * 3 * npix));
+      if (std::getenv("RPTGPU_PRINT_LAUNCH"))
+        std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp\n",
+                     flat ? "KdFlat" : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l);
       h->counters.alloc(4);
       h->pcounters.alloc(16);
       HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
@@ -331,7 +335,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         fr.sample_base = p->sample_index_base + s0;
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
         { Bracket b(h, RPT_K_PATHS, prof);
-          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks, h->all_flat && !h->dscene.force_general,
+          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks, flat,
                     h->flat_refs, h->flat_tris);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);

@@ -25,7 +25,7 @@ struct KernelTable {
   void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32);
   void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
   // persistent per-pixel kernel: resident 64-thread blocks per CU, and the launch
-  int (*paths_max_blocks_per_cu)();
+  int (*paths_max_blocks_per_cu)(bool flat);
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
                 uint32_t chunk, uint32_t nblocks, bool flat, uint32_t flat_refs, uint32_t flat_tris);
