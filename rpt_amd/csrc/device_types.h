@@ -55,6 +55,8 @@ struct alignas(16) Inst {
   double lin[9];    // linear (shape.rs:104)         — sampling only
   double scale;     // determinant (shape.rs:107)    — sampling only
   double plane[4];  // PLANE: normal xyz, value
+  double bounds[6]; // MESH / GROUP: a copy of trees[tree].bounds, so that a root slab test needs one scalar
+                    // round trip (this record) instead of two (record, then tree)
 };
 
 struct alignas(16) Tree {

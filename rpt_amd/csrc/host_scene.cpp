@@ -307,6 +307,7 @@ struct Flattener {
         }
         const rptdev::Tree& t = fs.trees[in.tree];
         for (int k = 0; k < 3; k++) { local.lo[k] = t.bounds[k]; local.hi[k] = t.bounds[3 + k]; }
+        std::memcpy(in.bounds, t.bounds, sizeof(in.bounds));
         break;
       }
       case RPT_SHAPE_GROUP: {
@@ -331,6 +332,7 @@ struct Flattener {
         in.tree = tr;
         const rptdev::Tree& t = fs.trees[tr];
         for (int k = 0; k < 3; k++) { local.lo[k] = t.bounds[k]; local.hi[k] = t.bounds[3 + k]; }
+        std::memcpy(in.bounds, t.bounds, sizeof(in.bounds));
         break;
       }
       default:
