@@ -79,7 +79,7 @@ struct rptgpu_scene {
   DevBuf<uint8_t> nrec;
   uint64_t ws_cap = 0;
   uint32_t ws_bounces = 0;
-  DevBuf<double> prec;                 // persistent kernel: depth records [bounces*8][threads]
+  DevBuf<double> prec;                 // persistent kernel: depth records [threads][bounces][8]
   DevBuf<double> lbuf;                 // persistent kernel: radiance of every sample of a launch [spp][3][npix]
   uint64_t lbuf_max_bytes = 32ull << 30; // cap on lbuf (RPTGPU_LBUF_BYTES); larger batches run as several launches
   uint32_t paths_chunk = 16;           // samples per work item (RPTGPU_PATHS_CHUNK)
