@@ -88,7 +88,8 @@ struct rptgpu_scene {
   bool prefer_wavefront = false; // scene has real kd-trees: traversal-latency bound
   bool all_flat = false;         // every tree is a single leaf (and the scene fits the LDS tables): the path kernel
                                  // without any traversal code
-  uint32_t flat_refs = 0, flat_tris = 0;
+  FlatLayout flat_layout{};        // the flat kernel's dynamic LDS
+  uint32_t flat_lds_bytes = 0;
   bool ext_shapes = false;       // scene has a shape only the *_ext kernel builds implement
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
@@ -313,15 +314,20 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
       }
       const bool flat = h->all_flat && !h->dscene.force_general;
-      int per_cu = kt->paths_max_blocks_per_cu(flat);
+      FlatLayout lay = h->flat_layout;
+      lay.rec_levels = std::min(lay.rec_levels, p->max_bounces);
+      if (const char* e = std::getenv("RPTGPU_FLAT_REC_LEVELS")) lay.rec_levels = std::min(lay.rec_levels, (uint32_t)std::max(0, std::atoi(e)));
+      const uint32_t flat_lds = flat ? lay.off_rec + lay.rec_levels * 4096u : 0u;
+      int per_cu = kt->paths_max_blocks_per_cu(flat, flat_lds);
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
       nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
       uint64_t nthreads = (uint64_t)nblocks * 64;
       h->prec.alloc(std::max<uint64_t>(1, (uint64_t)p->max_bounces) * rptdev::REC_FIELDS * nthreads);
       h->lbuf.alloc(std::max<uint64_t>(1, (uint64_t)spp_l * 3 * npix));
       if (std::getenv("RPTGPU_PRINT_LAUNCH"))
-        std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp\n",
-                     flat ? "KdFlat" : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l);
+        std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp, "
+                     "LDS %u B per wave (%u clamp-record levels)\n",
+                     flat ? "KdFlat" : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds, flat ? lay.rec_levels : 0u);
       h->counters.alloc(4);
       h->pcounters.alloc(16);
       HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
@@ -335,8 +341,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         fr.sample_base = p->sample_index_base + s0;
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
         { Bracket b(h, RPT_K_PATHS, prof);
-          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks, flat,
-                    h->flat_refs, h->flat_tris);
+          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks, flat ? &lay : nullptr,
+                    flat_lds);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
       }
@@ -525,9 +531,26 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     }
     h->all_flat = true;
     for (const rptdev::Tree& tr : fs.trees) h->all_flat = h->all_flat && tr.root_leaf != 0;
-    h->all_flat = h->all_flat && fs.refs.size() <= 64 && fs.tris.size() <= 64 && fs.num_objects <= 32; // FLAT_MAX*, kernels.inc
-    h->flat_refs = (uint32_t)fs.refs.size();
-    h->flat_tris = (uint32_t)fs.tris.size();
+    if (h->all_flat) { // does the scene fit a wave's share of LDS (160 KB per CU / 8 waves)?
+      constexpr uint32_t WAVE_LDS = 20480, REC_LEVEL = 4096; // 64 lanes x 8 doubles per clamp-record level
+      auto up16 = [](uint64_t v) { return (v + 15) & ~15ull; };
+      uint64_t off = 0;
+      FlatLayout lay{};
+      lay.n_refs = (uint32_t)fs.refs.size();
+      lay.n_tris = (uint32_t)fs.tris.size();
+      off = up16(fs.refs.size() * sizeof(rptdev::TriX));
+      lay.off_tris = (uint32_t)off; off = up16(off + fs.tris.size() * sizeof(rptdev::Tri));
+      lay.off_refs = (uint32_t)off; off = up16(off + fs.refs.size() * sizeof(uint32_t));
+      lay.off_mat = (uint32_t)off;  off = up16(off + (uint64_t)fs.num_objects * sizeof(rptdev::Material));
+      lay.off_leaf = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 16);
+      lay.off_rec = (uint32_t)off;
+      if (off > WAVE_LDS) {
+        h->all_flat = false;
+      } else {
+        lay.rec_levels = (uint32_t)((WAVE_LDS - off) / REC_LEVEL);
+        h->flat_layout = lay;
+      }
+    }
     h->ext_shapes = fs.nested_mesh;
     for (const rptdev::Inst& in : fs.insts) h->ext_shapes = h->ext_shapes || in.kind == RPT_SHAPE_MONOMIAL;
     for (const rptdev::Light& l : fs.lights) h->light_casts.push_back(l.kind != RPT_LIGHT_AMBIENT ? 1 : 0);

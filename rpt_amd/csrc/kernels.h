@@ -5,6 +5,13 @@
 
 #include "device_types.h"
 
+// layout of the flat path kernel's dynamic LDS (byte offsets; lrec at 0), see kernels.inc
+struct FlatLayout {
+  uint32_t off_tris, off_refs, off_mat, off_leaf, off_rec;
+  uint32_t rec_levels;
+  uint32_t n_refs, n_tris;
+};
+
 // buffers of the optional ray sort in front of a per-tree traversal (all sized for the query's n)
 struct SortBufs {
   uint32_t *keys_in, *keys_out, *vals_in;
@@ -25,10 +32,10 @@ struct KernelTable {
   void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32);
   void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
   // persistent per-pixel kernel: resident 64-thread blocks per CU, and the launch
-  int (*paths_max_blocks_per_cu)(bool flat);
+  int (*paths_max_blocks_per_cu)(bool flat, uint32_t flat_lds_bytes);
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
-                uint32_t chunk, uint32_t nblocks, bool flat, uint32_t flat_refs, uint32_t flat_tris);
+                uint32_t chunk, uint32_t nblocks, const FlatLayout* flat, uint32_t flat_lds_bytes);
   // pixel sums of a launch's samples, in sample order
   void (*sum_samples)(hipStream_t, const rptdev::Frame&, const double* lbuf, uint32_t spp, bool first);
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run
