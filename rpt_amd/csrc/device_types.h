@@ -69,6 +69,8 @@ struct alignas(16) Tree {
   uint32_t root_leaf; // 0, or 1 + the entry count when node 0 is a leaf (fewer than 16 primitives, kdtree.rs:236)
   uint32_t root_first; // that leaf's first entry in refs[] / lrec[]
   uint32_t _pad;
+  uint64_t sample_zone; // rand 0.8 UniformInt zone for Uniform::from(0..num_prims): u64::MAX - (2^64 - n) % n,
+  uint64_t _pad2;       // precomputed because a 64-bit modulo costs ~200 device instructions per light sample
 };
 
 struct alignas(16) Material {

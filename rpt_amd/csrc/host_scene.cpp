@@ -214,6 +214,10 @@ struct Flattener {
     t.ref_base = (uint32_t)fs.refs.size();
     t.prim_base = prim_base;
     t.num_prims = (uint32_t)boxes.size();
+    if (t.num_prims) { // uniform.rs (rand 0.8.3) UniformInt::<usize>::sample: ints_to_reject = (MAX - range + 1) % range
+      uint64_t n = t.num_prims;
+      t.sample_zone = 0xFFFFFFFFFFFFFFFFull - (0xFFFFFFFFFFFFFFFFull - n + 1) % n;
+    }
     t.regular = kb.regular ? 1u : 0u;
     if (!kb.nodes.empty() && (kb.nodes[0].ib & 3u) == 3u) {
       t.root_leaf = 1u + (kb.nodes[0].ib >> 2);
