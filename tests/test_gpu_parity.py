@@ -408,6 +408,64 @@ def test_edge_cases_match_the_oracle(oracle):
         g.close()
 
 
+def _polygon_room(n_walls, transformed_every=0, sides=(4, 5, 6, 8), seed=3):
+    """Many small polygon meshes in a row (single-leaf trees), optionally with a Transformed one every few
+    objects and a cube / sphere in between: the shapes the flat path kernel batches or must not batch."""
+    rs = np.random.RandomState(seed)
+    scene = rpt_amd.Scene()
+    for i in range(n_walls):
+        k = sides[i % len(sides)]
+        c = rs.uniform(-2.0, 2.0, 3)
+        a = rs.randn(3)
+        a /= np.linalg.norm(a)
+        b = np.cross(a, rs.randn(3))
+        b /= np.linalg.norm(b)
+        r = rs.uniform(0.5, 1.5)
+        verts = [tuple(c + r * (math.cos(t) * a + math.sin(t) * b)) for t in np.linspace(0, 2 * math.pi, k, endpoint=False)]
+        shape = rpt_amd.polygon(verts)
+        if transformed_every and i % transformed_every == transformed_every - 1:
+            shape = shape.rotate_y(0.3 * i).translate((0.1 * i, 0.0, -0.05 * i))
+        mat = rpt_amd.Material.diffuse(tuple(rs.uniform(0.3, 0.9, 3))) if i % 3 else rpt_amd.Material.specular(tuple(rs.uniform(0.3, 0.9, 3)), 0.2)
+        scene.add(rpt_amd.Object(shape).material(mat))
+        if i % 7 == 3:
+            scene.add(rpt_amd.Object(rpt_amd.cube().scale((0.4, 0.4, 0.4)).translate(tuple(rs.uniform(-1.5, 1.5, 3))))
+                      .material(rpt_amd.Material.diffuse((0.8, 0.8, 0.8))))
+        if i % 7 == 5:
+            scene.add(rpt_amd.Object(rpt_amd.sphere().scale((0.3, 0.3, 0.3)).translate(tuple(rs.uniform(-1.5, 1.5, 3)))))
+    quad = rpt_amd.polygon([(-0.5, 2.9, -0.5), (-0.5, 2.9, 0.5), (0.5, 2.9, 0.5), (0.5, 2.9, -0.5)])
+    scene.add(rpt_amd.Light.Object(rpt_amd.Object(quad).material(rpt_amd.Material.light((1.0, 1.0, 0.9), 30.0))))
+    scene.add(rpt_amd.Light.Point((20.0, 20.0, 20.0), (0.0, 0.0, 4.0)))
+    cam = rpt_amd.Camera.look_at((0.0, 0.5, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.9)
+    return scene, cam
+
+
+import math  # noqa: E402
+
+
+@pytest.mark.parametrize("n_walls,transformed_every", [(5, 0), (9, 0), (14, 4), (23, 0), (40, 5), (160, 7)])
+def test_flat_scenes_batched_leaf_tests_match_the_oracle(oracle, n_walls, transformed_every):
+    # runs of 5 (one batch), 9 and 14 (split at FLAT_RUN = 6 / at Transformed meshes / at cubes and spheres),
+    # polygons of 2..6 triangles (leaf loops of different lengths inside one wave), and scenes whose tables
+    # do or do not fit a wave's LDS share (160 walls: the general kernel takes over) — all bit-equal to the oracle
+    scene, cam = _polygon_room(n_walls, transformed_every)
+    p = make_params(48, 32, 4, 3, seed=1000 + n_walls)
+    g = GpuScene(scene, 0)
+    ref = oracle.OracleScene(scene).render(cam, p, threads=0)
+    for flags in (0, _abi.RPT_FLAG_PERSISTENT, _abi.RPT_FLAG_PERSISTENT | _abi.RPT_FLAG_GENERAL_TRAVERSAL, _abi.RPT_FLAG_WAVEFRONT):
+        pp = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=flags)
+        img = g.render_batch(cam, pp)
+        assert (img == ref).all(), (n_walls, flags, np.abs(img - ref).max())
+    # closest hits and random secondary rays through rptgpu_closest_hit as well
+    rs = np.random.RandomState(n_walls)
+    o = rs.uniform(-2.5, 2.5, (4000, 3))
+    d = rs.randn(4000, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0, n0, ob0 = oracle.OracleScene(scene).closest_hit(o, d)
+    t1, n1, ob1 = g.closest_hit(o, d)
+    assert (t0 == t1).all() and (ob0 == ob1).all() and (n0.view(np.int64) == n1.view(np.int64)).all()
+    g.close()
+
+
 def test_too_deep_tree_is_rejected():
     # a chain of nested shells forces one split per level: deeper than the 32-entry device stack
     tris = []
