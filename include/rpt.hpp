@@ -13,8 +13,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <functional>
+#include <istream>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -274,6 +277,139 @@ inline Shape polygon(const std::vector<Vec3>& verts) { // shape.rs:307-313
   std::vector<Triangle> tris;
   for (size_t i = 1; i + 1 < verts.size(); i++) tris.push_back(Triangle::from_vertices(verts[0], verts[i], verts[i + 1]));
   return Mesh(tris);
+}
+
+// ---------------------------------------------------------------------------- asset import (src/io.rs)
+// Same parsing rules as the reference: fan triangulation (io.rs:181-198), negative indices count from the
+// end (io.rs:10-18), a corner without a normal index makes the whole triangle flat (io.rs:186-187); STL is
+// binary when size == 84 + 50 n, else ASCII when it starts with "solid " (io.rs:260-287).
+namespace io_detail {
+inline std::vector<std::string> tokens(const std::string& line) {
+  std::vector<std::string> t;
+  std::istringstream ss(line);
+  std::string w;
+  while (ss >> w) t.push_back(w);
+  return t;
+}
+inline double number(const std::string& s) {
+  char* end = nullptr;
+  double v = std::strtod(s.c_str(), &end);
+  if (end == s.c_str() || *end != '\0') throw std::runtime_error("Failed to parse number in asset file: " + s);
+  return v;
+}
+inline bool parse_index(const std::string& value, size_t len, size_t& out) { // io.rs:10-18
+  if (value.empty()) return false;
+  char* end = nullptr;
+  long long index = std::strtoll(value.c_str(), &end, 10);
+  if (end == value.c_str() || *end != '\0') return false;
+  out = index > 0 ? (size_t)(index - 1) : (size_t)((long long)len + index);
+  return true;
+}
+inline Vec3 point(const std::vector<std::string>& t) { // parse_obj_point io.rs:150-161
+  if (t.size() < 4) throw std::runtime_error("Failed to parse vertex in .OBJ");
+  return {number(t[1]), number(t[2]), number(t[3])};
+}
+inline void face(const std::vector<std::string>& t, const std::vector<Vec3>& vertices, const std::vector<Vec3>& normals,
+                 std::vector<Triangle>& out) { // parse_obj_face io.rs:163-200
+  std::vector<size_t> vi, vni;
+  std::vector<bool> has_n;
+  for (size_t k = 1; k < t.size(); k++) {
+    std::string args[3];
+    size_t a = 0;
+    for (char ch : t[k]) {
+      if (ch == '/') { if (++a > 2) break; }
+      else args[a] += ch;
+    }
+    size_t v = 0, n = 0;
+    if (!parse_index(args[0], vertices.size(), v)) throw std::runtime_error("Invalid vertex index");
+    vi.push_back(v);
+    has_n.push_back(parse_index(args[2], normals.size(), n));
+    vni.push_back(n);
+  }
+  for (size_t i = 1; i + 1 < vi.size(); i++) {
+    const size_t a = 0, b = i, c = i + 1;
+    if (!has_n[a] || !has_n[b] || !has_n[c]) {
+      out.push_back(Triangle::from_vertices(vertices.at(vi[a]), vertices.at(vi[b]), vertices.at(vi[c])));
+    } else {
+      out.push_back(Triangle{vertices.at(vi[a]), vertices.at(vi[b]), vertices.at(vi[c]), normals.at(vni[a]),
+                             normals.at(vni[b]), normals.at(vni[c])});
+    }
+  }
+}
+} // namespace io_detail
+
+inline Shape load_obj(std::istream& in) { // io.rs:27-74
+  std::vector<Vec3> vertices, normals;
+  std::vector<Triangle> triangles;
+  std::string line;
+  while (std::getline(in, line)) {
+    std::vector<std::string> t = io_detail::tokens(line);
+    if (t.empty() || t[0][0] == '#') continue;
+    if (t[0] == "v") vertices.push_back(io_detail::point(t));
+    else if (t[0] == "vn") normals.push_back(io_detail::point(t));
+    else if (t[0] == "f") io_detail::face(t, vertices, normals, triangles);
+  }
+  return Mesh(triangles);
+}
+inline Shape load_obj(const std::string& path) {
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  return load_obj(f);
+}
+
+inline Shape load_stl(const std::string& path) { // io.rs:260-360
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  const size_t size = data.size();
+  if (size < 15) throw std::runtime_error("Loaded .STL file is too short");
+  std::vector<Triangle> tris;
+  if (size >= 84) {
+    uint32_t n = 0;
+    std::memcpy(&n, data.data() + 80, 4);
+    if (size == 84 + (size_t)n * 50) { // very likely binary
+      for (uint32_t i = 0; i < n; i++) {
+        float v[12];
+        std::memcpy(v, data.data() + 84 + (size_t)i * 50, sizeof v);
+        Vec3 vn{(double)v[0], (double)v[1], (double)v[2]}; // f32 -> f64, as the reference does
+        tris.push_back(Triangle{{(double)v[3], (double)v[4], (double)v[5]}, {(double)v[6], (double)v[7], (double)v[8]},
+                                {(double)v[9], (double)v[10], (double)v[11]}, vn, vn, vn});
+      }
+      return Mesh(tris);
+    }
+  }
+  if (data.compare(0, 6, "solid ") == 0) {
+    std::vector<std::string> lines;
+    std::istringstream ss(data);
+    std::string line;
+    while (std::getline(ss, line)) lines.push_back(line);
+    auto trim = [](const std::string& s) {
+      size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+      return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+    };
+    for (size_t i = 1; i < lines.size();) {
+      std::string l = trim(lines[i]);
+      if (l.compare(0, 13, "facet normal ") != 0) {
+        if (l.empty() || l.compare(0, 8, "endsolid") == 0) { i++; continue; }
+        throw std::runtime_error("Malformed STL file: expected `facet normal`");
+      }
+      std::vector<std::string> nt = io_detail::tokens(l.substr(13));
+      if (nt.size() < 3 || i + 4 >= lines.size()) throw std::runtime_error("Malformed STL file");
+      Vec3 vn{io_detail::number(nt[0]), io_detail::number(nt[1]), io_detail::number(nt[2])};
+      Vec3 vs[3];
+      for (int j = 0; j < 3; j++) {
+        std::string vl = trim(lines[i + 2 + j]);
+        if (vl.compare(0, 7, "vertex ") != 0) throw std::runtime_error("Malformed STL file: expected `vertex`");
+        std::vector<std::string> vt = io_detail::tokens(vl.substr(7));
+        if (vt.size() < 3) throw std::runtime_error("Malformed STL file");
+        vs[j] = {io_detail::number(vt[0]), io_detail::number(vt[1]), io_detail::number(vt[2])};
+      }
+      tris.push_back(Triangle{vs[0], vs[1], vs[2], vn, vn, vn});
+      i += 7;
+    }
+    return Mesh(tris);
+  }
+  throw std::runtime_error("Loaded .STL file, but could not determine format");
 }
 
 // ---- object.rs:10-31 ----

@@ -136,3 +136,46 @@ def test_reference_assets_load_and_build(name, kind):
     assert a["max_depth"] == b["max_depth"] and a["max_depth"] <= 32
     for k in ("split", "info", "a", "b", "refs"):
         assert a[k].shape == b[k].shape and (a[k] == b[k]).all(), k
+
+
+def _cpp_io_check():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "build", "io_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples"), "build/io_check"])
+    return exe
+
+
+def _cpp_rows(path):
+    import subprocess
+    out = subprocess.check_output([_cpp_io_check(), str(path)], text=True).split("\n")
+    n = int(out[0])
+    rows = np.array([[float.fromhex(x) for x in line.split()] for line in out[1:1 + n]], dtype=np.float64).reshape(n, 18)
+    return rows
+
+
+def test_cpp_mirror_loaders_equal_the_python_mirror(tmp_path):
+    # include/rpt.hpp load_obj / load_stl (reference src/io.rs) against rpt_amd.io, bit for bit
+    p = tmp_path / "a.obj"
+    p.write_text(OBJ)
+    assert (_cpp_rows(p) == load_obj(str(p)).triangles).all()
+    rows = scenes.knot_mesh(12, 5)
+    q = tmp_path / "b.stl"
+    with open(q, "wb") as f:
+        f.write(b"\0" * 80 + struct.pack("<I", len(rows)))
+        for r in rows:
+            f.write(struct.pack("<12fH", *r[9:12].astype(np.float32), *r[0:9].astype(np.float32), 0))
+    assert (_cpp_rows(q) == load_stl(str(q)).triangles).all()
+    a = tmp_path / "c.stl"
+    a.write_text("solid t\n" + "".join(
+        "facet normal %r %r %r\n outer loop\n  vertex %r %r %r\n  vertex %r %r %r\n  vertex %r %r %r\n endloop\nendfacet\n"
+        % tuple(float(x) for x in np.concatenate([r[9:12], r[0:9]])) for r in rows[:7]) + "endsolid t\n")
+    assert (_cpp_rows(a) == load_stl(str(a)).triangles).all()
+    import os
+    for name in ("teapot.obj", "cylinder.stl"):  # the reference's own assets, when present
+        path = os.path.join(REF_EXAMPLES, name)
+        if os.path.exists(path):
+            ref = (load_obj(path) if name.endswith(".obj") else load_stl(path)).triangles
+            assert (_cpp_rows(path) == ref).all(), name
