@@ -162,6 +162,17 @@ def cross(a, b):
     return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
 
 
+def _ieee_div(a, b):
+    """a / b as IEEE (and Rust) define it: Python raises on a zero divisor instead."""
+    if b != 0.0:
+        return a / b
+    if a == 0.0 or a != a:
+        return math.nan
+    return math.copysign(math.inf, a) * math.copysign(1.0, b)
+
+
 def normalize(a):
+    # glm::normalize of a zero vector is (NaN, NaN, NaN) in the reference (a degenerate triangle's normal,
+    # mesh.rs:25-36), not an error
     n = math.sqrt(dot(a, a))
-    return (a[0] / n, a[1] / n, a[2] / n)
+    return (_ieee_div(a[0], n), _ieee_div(a[1], n), _ieee_div(a[2], n))

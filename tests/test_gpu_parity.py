@@ -467,6 +467,56 @@ def test_flat_scenes_batched_leaf_tests_match_the_oracle(oracle, n_walls, transf
     g.close()
 
 
+def test_flat_scenes_exact_ties_and_coplanar_surfaces(oracle):
+    # adversarial for the batched leaf tests: the same quad twice (exact ties: the first object must win), a cube
+    # standing on a coplanar floor quad, quads that share edges and corners, a quad inside another quad's plane,
+    # a Transformed copy of an untransformed quad (same place, different arithmetic), zero-area and sliver triangles
+    S = rpt_amd.Scene()
+    floor = [(-2.0, 0.0, -2.0), (-2.0, 0.0, 2.0), (2.0, 0.0, 2.0), (2.0, 0.0, -2.0)]
+    S.add(rpt_amd.Object(rpt_amd.polygon(floor)).material(rpt_amd.Material.diffuse((0.7, 0.7, 0.7))))
+    S.add(rpt_amd.Object(rpt_amd.polygon(floor)).material(rpt_amd.Material.diffuse((0.9, 0.1, 0.1))))        # duplicate
+    S.add(rpt_amd.Object(rpt_amd.polygon([(-1.0, 0.0, -1.0), (-1.0, 0.0, 1.0), (1.0, 0.0, 1.0), (1.0, 0.0, -1.0)]))
+          .material(rpt_amd.Material.specular((0.1, 0.9, 0.1), 0.3)))                                          # coplanar inset
+    S.add(rpt_amd.Object(rpt_amd.polygon([(-2.0, 0.0, -2.0), (-2.0, 2.0, -2.0), (2.0, 2.0, -2.0), (2.0, 0.0, -2.0)]))
+          .material(rpt_amd.Material.diffuse((0.2, 0.2, 0.9))))                                                # shares an edge
+    S.add(rpt_amd.Object(rpt_amd.polygon([(-2.0, 0.0, -2.0), (-2.0, 0.0, 2.0), (-2.0, 2.0, 2.0), (-2.0, 2.0, -2.0)]))
+          .material(rpt_amd.Material.diffuse((0.9, 0.9, 0.2))))                                                # shares a corner
+    S.add(rpt_amd.Object(rpt_amd.polygon([(0.0, 0.5, 0.0), (0.0, 0.5, 0.0), (1.0, 0.5, 0.0), (1.0, 0.5000000001, 1e-9)]))
+          .material(rpt_amd.Material.diffuse((0.5, 0.5, 0.5))))                                                # degenerate + sliver
+    S.add(rpt_amd.Object(rpt_amd.cube().translate((0.5, 0.5, 0.5))).material(rpt_amd.Material.clear(1.5, 0.05)))  # on the floor
+    S.add(rpt_amd.Object(rpt_amd.polygon(floor).translate((0.0, 0.0, 0.0))).material(rpt_amd.Material.diffuse((0.3, 0.8, 0.8))))
+    S.add(rpt_amd.Object(rpt_amd.polygon(floor).rotate_y(math.pi / 2)).material(rpt_amd.Material.diffuse((0.8, 0.3, 0.8))))
+    S.add(rpt_amd.Light.Object(rpt_amd.Object(rpt_amd.polygon([(-0.5, 1.9, -0.5), (-0.5, 1.9, 0.5), (0.5, 1.9, 0.5), (0.5, 1.9, -0.5)]))
+                               .material(rpt_amd.Material.light((1.0, 1.0, 1.0), 20.0))))
+    S.add(rpt_amd.Light.Directional((0.3, 0.3, 0.3), (0.0, -1.0, 0.0)))                                        # axis-parallel shadow rays
+    cam = rpt_amd.Camera.look_at((0.3, 1.2, 3.5), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 0.9)
+    g = GpuScene(S, 0)
+    osc = oracle.OracleScene(S)
+    p = make_params(64, 40, 5, 4, seed=77)
+    ref = osc.render(cam, p, threads=0)
+    for flags in (0, _abi.RPT_FLAG_PERSISTENT | _abi.RPT_FLAG_GENERAL_TRAVERSAL, _abi.RPT_FLAG_WAVEFRONT):
+        img = g.render_batch(cam, make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=flags))
+        same = (img == ref) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), (flags, np.abs(img - ref).max())
+    # rays aimed exactly at shared edges / corners / along the planes
+    rs = np.random.RandomState(2)
+    tgt = np.array([(-2.0, 0.0, -2.0), (-2.0, 1.0, -2.0), (0.0, 0.0, -2.0), (1.0, 0.0, 1.0), (0.0, 0.0, 0.0), (0.5, 0.0, 0.5),
+                    (1.0, 0.5, 0.0), (0.0, 1.0, 0.0)])
+    o = rs.uniform(-1.5, 1.5, (len(tgt) * 200, 3)) + np.array([0.0, 1.6, 0.0])
+    d = np.repeat(tgt, 200, axis=0) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o2 = np.array([[0.0, 1e-9, 0.0], [0.0, 0.0, 0.0], [-3.0, 0.0, 0.0], [0.25, 1.0, 0.25]])
+    d2 = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    t0, n0, ob0 = osc.closest_hit(o, d)
+    t1, n1, ob1 = g.closest_hit(o, d)
+    same_t = (t0.view(np.int64) == t1.view(np.int64)) | (np.isnan(t0) & np.isnan(t1))
+    assert same_t.all() and (ob0 == ob1).all()
+    assert ((n0.view(np.int64) == n1.view(np.int64)) | (np.isnan(n0) & np.isnan(n1))).all()
+    assert (ob0 == 0).sum() > 0 and (ob0 == 1).sum() == 0   # the duplicate never wins a tie against the first
+    g.close()
+
+
 def test_too_deep_tree_is_rejected():
     # a chain of nested shells forces one split per level: deeper than the 32-entry device stack
     tris = []
