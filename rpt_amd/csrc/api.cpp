@@ -89,6 +89,7 @@ struct rptgpu_scene {
   bool all_flat = false;         // every tree is a single leaf (and the scene fits the LDS tables): the path kernel
                                  // without any traversal code
   FlatLayout flat_layout{};        // the flat kernel's dynamic LDS
+  DevBuf<double> plane_vals;       // distinct bounding-plane coordinates of the untransformed meshes [3][4]
   uint32_t flat_lds_bytes = 0;
   bool ext_shapes = false;       // scene has a shape only the *_ext kernel builds implement
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
@@ -543,6 +544,51 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       lay.off_refs = (uint32_t)off; off = up16(off + fs.refs.size() * sizeof(uint32_t));
       lay.off_mat = (uint32_t)off;  off = up16(off + (uint64_t)fs.num_objects * sizeof(rptdev::Material));
       lay.off_leaf = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 16);
+      // shared slab quotients: distinct plane coordinates per axis over the untransformed meshes (bitwise
+      // distinct: -0.0 and 0.0 give differently signed zeros), at most 4 per axis or the feature stays off
+      std::vector<double> planes(12, 0.0);
+      uint32_t cnt[3] = {0, 0, 0};
+      bool planes_ok = true;
+      auto slot_of = [&](int axis, double v) -> int {
+        uint64_t bits;
+        std::memcpy(&bits, &v, 8);
+        for (uint32_t j = 0; j < cnt[axis]; j++) {
+          uint64_t b2;
+          std::memcpy(&b2, &planes[axis * 4 + j], 8);
+          if (b2 == bits) return axis * 4 + (int)j;
+        }
+        if (cnt[axis] == 4) return -1;
+        planes[axis * 4 + cnt[axis]] = v;
+        return axis * 4 + (int)cnt[axis]++;
+      };
+      static const int FACE[6] = {0, 3, 1, 4, 2, 5}; // bounds[] index of the faces in div6's order
+      std::vector<uint32_t> idx(fs.num_objects, 0);
+      for (int i = 0; i < fs.num_objects && planes_ok; i++) {
+        const rptdev::Inst& in = fs.insts[i];
+        if (in.kind != RPT_SHAPE_MESH || in.has_xf) continue;
+        for (int k = 0; k < 6; k++) {
+          int sl = slot_of(FACE[k] % 3, in.bounds[FACE[k]]);
+          if (sl < 0) { planes_ok = false; break; }
+          idx[i] |= (uint32_t)sl << (4 * k);
+        }
+      }
+      if (planes_ok && cnt[0] + cnt[1] + cnt[2] > 0 && !std::getenv("RPTGPU_NO_PLANE_TABLE")) {
+        for (int i = 0; i < fs.num_objects; i++) {
+          rptdev::Inst& in = fs.insts[i];
+          if (in.kind == RPT_SHAPE_MESH && !in.has_xf) { in.plane_idx = idx[i]; in.plane_use = 1; }
+        }
+        // plane_use = number of consecutive table users starting here, capped at the device's run length (6)
+        for (int i = fs.num_objects - 1; i >= 0; i--) {
+          rptdev::Inst& in = fs.insts[i];
+          if (!in.plane_use) continue;
+          uint32_t next = (i + 1 < fs.num_objects) ? fs.insts[i + 1].plane_use : 0u;
+          in.plane_use = std::min<uint32_t>(6u, 1u + next);
+        }
+        lay.plane_cnt = cnt[0] | (cnt[1] << 4) | (cnt[2] << 8);
+        lay.off_qtab = (uint32_t)off; off = up16(off + 12 * 64 * sizeof(double));
+        h->plane_vals.upload(planes, h->stream);
+        lay.plane_vals = h->plane_vals.p;
+      }
       lay.off_rec = (uint32_t)off;
       if (off > WAVE_LDS) {
         h->all_flat = false;

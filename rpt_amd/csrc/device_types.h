@@ -57,6 +57,10 @@ struct alignas(16) Inst {
   double plane[4];  // PLANE: normal xyz, value
   double bounds[6]; // MESH / GROUP: a copy of trees[tree].bounds, so that a root slab test needs one scalar
                     // round trip (this record) instead of two (record, then tree)
+  // flat scenes: where the six slab quotients of this (untransformed) mesh sit in the per-ray plane table —
+  // 4 bits per face in the order bounds[0], [3], [1], [4], [2], [5]; slot = axis * 4 + index (kernels/paths.inc)
+  uint32_t plane_idx;
+  uint32_t plane_use;
 };
 
 struct alignas(16) Tree {

@@ -10,6 +10,11 @@ struct FlatLayout {
   uint32_t off_tris, off_refs, off_mat, off_leaf, off_rec;
   uint32_t rec_levels;
   uint32_t n_refs, n_tris;
+  // distinct bounding-plane coordinates of the untransformed meshes, at most 4 per axis: the quotient
+  // (value - o) / d of each is computed ONCE per ray into off_qtab ([12 slots][64 lanes] doubles) and shared
+  // by every mesh whose box uses that plane (the walls of C2 have 30 faces on 6 distinct planes)
+  uint32_t off_qtab, plane_cnt;  // plane_cnt: 4 bits per axis; 0 = feature off
+  const double* plane_vals;      // [3][4] in device memory
 };
 
 // buffers of the optional ray sort in front of a per-tree traversal (all sized for the query's n)
