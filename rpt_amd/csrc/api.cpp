@@ -577,12 +577,12 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
           rptdev::Inst& in = fs.insts[i];
           if (in.kind == RPT_SHAPE_MESH && !in.has_xf) { in.plane_idx = idx[i]; in.plane_use = 1; }
         }
-        // plane_use = number of consecutive table users starting here, capped at the device's run length (6)
+        // plane_use = number of consecutive table users starting here, capped at the device's run length
         for (int i = fs.num_objects - 1; i >= 0; i--) {
           rptdev::Inst& in = fs.insts[i];
           if (!in.plane_use) continue;
           uint32_t next = (i + 1 < fs.num_objects) ? fs.insts[i + 1].plane_use : 0u;
-          in.plane_use = std::min<uint32_t>(6u, 1u + next);
+          in.plane_use = std::min<uint32_t>((uint32_t)RPT_FLAT_RUN, 1u + next);
         }
         lay.plane_cnt = cnt[0] | (cnt[1] << 4) | (cnt[2] << 8);
         lay.off_qtab = (uint32_t)off; off = up16(off + 12 * 64 * sizeof(double));

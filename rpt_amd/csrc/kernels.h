@@ -5,6 +5,11 @@
 
 #include "device_types.h"
 
+// meshes per batched run of the flat path kernel (kernels/paths.inc flat_query; api.cpp caps Inst::plane_use with it)
+#ifndef RPT_FLAT_RUN
+#define RPT_FLAT_RUN 6
+#endif
+
 // layout of the flat path kernel's dynamic LDS (byte offsets; lrec at 0), see kernels.inc
 struct FlatLayout {
   uint32_t off_tris, off_refs, off_mat, off_leaf, off_rec;
