@@ -2,14 +2,17 @@
 """bench.py — Msamples/s of the rpt hot path on MI355X (BASELINE.json metric).
 
 A step = one complete frame of BASELINE configs[1]: examples/cornell.rs geometry, 1920x1080,
-8 bounces, 512 samples per pixel (override with --spp), through the C ABI
-(rptgpu_render_batch_device) in parity mode (IEEE f64, no FMA contraction).  The frame stays in
-HBM inside the timed region; with N GPUs rank r renders the tiles tile_id % N == r of the SAME
-frame (strong scaling) and the f32 framebuffers are summed to rank 0 by one RCCL reduce per step.
+8 bounces, 512 samples per pixel (override with --spp), through the C ABI in parity mode (IEEE f64,
+no FMA contraction).  The timed region is what `Renderer::sample` covers (SURVEY §8d): ray generation
+through the last bounce, the reduce over ranks, and the write of the W*H mean colours into HOST memory
+(rank 0); scene construction (kd build + upload) is outside it and reported as `scene_create_ms` /
+`wall_clock_per_frame_ms`.  With N GPUs rank r renders the tiles tile_id % N == r of the SAME frame
+(strong scaling) and the f32 framebuffers are summed to rank 0 by one RCCL reduce per step.
 
     python bench.py                      # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --scene dragon --spp 16          # another BASELINE config at ITS frame size
 """
 import argparse
 import json
@@ -52,7 +55,39 @@ def algorithmic_bytes(c, env_is_hdri):
     raygen = c["samples"] * RAY_IO // 2
     parts = {"rpt_raygen": raygen, "rpt_extend": ext, "rpt_shade": shade, "rpt_shadow": sha, "rpt_resolve": resolve}
     parts["rpt_paths"] = sum(parts.values())  # the persistent kernel does all of it in one launch
+    # the per-tree traversal kernel on its own: what KdTree::intersect reads below the root slab test
+    # (kdtree.rs:151-223) for closest-hit and shadow rays together, plus one ray in / one record out per root test
+    parts["rpt_tree_trace"] = ((c["n_root"] + c["n_root_sh"]) * RAY_IO
+                               + (c["n_inner"] + c["n_inner_sh"]) * NODE + (c["n_leaf"] + c["n_leaf_sh"]) * LEAF
+                               + (c["n_ref"] + c["n_ref_sh"]) * REF + (c["n_tri"] + c["n_tri_sh"]) * TRI)
     return parts
+
+
+def host_cpus():
+    """threads this process may actually run on (affinity mask and cgroup quota), and the raw count"""
+    raw = os.cpu_count() or 1
+    n = raw
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(float(q[0]) / float(q[1]))))
+    except Exception:
+        pass
+    return n, raw
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def main():
@@ -60,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per step (default: the config's 512)")
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per step (default: the config's own)")
     ap.add_argument("--scene", default="cornell", choices=sorted(scenes.SCENES))
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -68,9 +103,10 @@ def main():
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--cpu-spp", type=int, default=None, help="spp of the CPU-baseline sample (default: ~15 s of CPU work)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last step's reduced f32 frame (.npy)")
     ap.add_argument("--fixed-samples", action="store_true", help="every step renders the same samples (tests)")
+    ap.add_argument("--pmc-json", default=None, help="rocprofv3 PMC summary of this workload (default: profiles/<latest>_<scene>_pmc.json)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,15 +127,19 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     scene, camera, cfg = scenes.SCENES[args.scene]()
-    W = args.width or (cfg["width"] if args.scene == "cornell" else min(cfg["width"], 1920))
-    H = args.height or (cfg["height"] if args.scene == "cornell" else min(cfg["height"], 1080))
+    W = args.width or cfg["width"]
+    H = args.height or cfg["height"]
     B = args.bounces if args.bounces is not None else cfg["max_bounces"]
     spp = args.spp or cfg["num_samples"]
     precision = _abi.RPT_PRECISION_F64_STRICT if args.mode == "strict" else _abi.RPT_PRECISION_F64_FAST
 
     pipe_flag = {"auto": 0, "persistent": _abi.RPT_FLAG_PERSISTENT, "wavefront": _abi.RPT_FLAG_WAVEFRONT}[args.pipeline]
-    gpu = rpt_amd.GpuScene(scene, local_rank)
+    torch.cuda.synchronize()
+    t_create = time.perf_counter()
+    gpu = rpt_amd.GpuScene(scene, local_rank)  # flatten + kd build (reference rule) + upload
+    scene_create_ms = (time.perf_counter() - t_create) * 1e3
     frame = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
+    host_frame = torch.empty(W * H * 3, dtype=torch.float32).pin_memory() if rank == 0 else None
     render_part = D.gpu_render_part(gpu, camera)
     step_no = [0]
 
@@ -107,6 +147,8 @@ def main():
         p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=0 if args.fixed_samples else step_no[0] * spp,
                         precision=precision, flags=_abi.RPT_FLAG_PROFILE_KERNELS | pipe_flag)
         D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
+        if rank == 0:  # Renderer::sample ends with the colours in host memory (renderer.rs:127-128)
+            host_frame.copy_(frame, non_blocking=False)
         step_no[0] += 1
 
     def fence():
@@ -131,13 +173,14 @@ def main():
     st = gpu.stats()
 
     if rank == 0 and args.dump_frame:
-        np.save(args.dump_frame, frame.cpu().numpy())
+        np.save(args.dump_frame, host_frame.numpy())
     if rank == 0:
         total_samples = float(W) * H * spp * args.steps
         value = total_samples / elapsed / 1e6
-        names = [gpu.lib.rptgpu_kernel_name(k).decode() for k in range(6)]
-        kern_ms = {names[k]: st.kernel_ms[k] for k in range(6)}
-        kern_n = {names[k]: int(st.kernel_launches[k]) for k in range(6)}
+        NK = _abi.RPT_K_COUNT
+        names = [gpu.lib.rptgpu_kernel_name(k).decode() for k in range(NK)]
+        kern_ms = {names[k]: st.kernel_ms[k] for k in range(NK)}
+        kern_n = {names[k]: int(st.kernel_launches[k]) for k in range(NK)}
         names = [k for k in names if kern_n[k] > 0]
 
         # visit counts of the reference algorithm for this workload, from the instrumented oracle
@@ -149,7 +192,14 @@ def main():
         rank_samples = float(st.samples)  # what THIS rank traced in the timed region
         scale = rank_samples / max(1, cnt["samples"])
         bytes_k = {k: v * scale for k, v in algorithmic_bytes(cnt, scene.environment.hdri is not None).items()}
-        dominant = max(kern_ms, key=kern_ms.get)
+        bytes_k["rpt_tree_enter+sort"] = 0.0
+        # the kernel the roofline line is about: the one with the most time among the disjoint kinds, or the
+        # per-tree traversal when it is the bulk of the queries that contain it (scenes with deep trees)
+        disjoint = {k: kern_ms[k] for k in names if k not in ("rpt_tree_trace", "rpt_tree_enter+sort")}
+        dominant = max(disjoint, key=disjoint.get)
+        if "rpt_tree_trace" in names and kern_ms["rpt_tree_trace"] >= 0.5 * (kern_ms.get("rpt_extend", 0) + kern_ms.get("rpt_shadow", 0)) \
+                and dominant in ("rpt_extend", "rpt_shadow"):
+            dominant = "rpt_tree_trace"
         kernels = {}
         for k in names:
             ms, n = kern_ms[k], max(1, kern_n[k])
@@ -157,33 +207,66 @@ def main():
                           "alg_GB_per_launch": bytes_k[k] / n / 1e9,
                           "achieved_GBs": (bytes_k[k] / 1e9) / (ms / 1e3) if ms > 0 else None}
         ach = kernels[dominant]["achieved_GBs"]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath)).get(dominant, {})
-                if "hbm_bytes_per_sample" in tj:  # measured per sample (PMC run), scaled to this launch size
-                    traffic = tj["hbm_bytes_per_sample"] * rank_samples / max(1, kern_n[dominant])
-                else:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
                     "alg_bytes_per_sample": bytes_k["rpt_paths"] / rank_samples,
-                    "kernels": kernels,
-                    "note": "compute/latency-bound f64 scalar work on an L2-resident scene; HBM fraction is low by construction (DESIGN.md)"}
+                    "achieved_is": "SURVEY §8d algorithmic bytes of the REFERENCE traversal / launch time (an accounting "
+                                   "figure); hbm_measured_GBs is what the fabric counters saw",
+                    "kernels": kernels}
+        # measured counters of the same workload (rocprofv3 PMC passes, scripts/profile.sh + summarize_profile.py)
+        pmc_path = args.pmc_json
+        if pmc_path is None:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % args.scene)))
+            pmc_path = cands[-1] if cands else None
+        if pmc_path and os.path.exists(pmc_path):
+            try:
+                pj = json.load(open(pmc_path))
+                k = pj.get("kernels", {}).get(dominant)
+                if k:
+                    n_l = max(1, kern_n[dominant])
+                    roofline["pmc_source"] = "%s (%s)" % (os.path.relpath(pmc_path, ROOT), pj.get("workload", ""))
+                    if k.get("hbm_bytes_per_sample") is not None:
+                        roofline["traffic"] = k["hbm_bytes_per_sample"] * rank_samples / n_l
+                        roofline["hbm_measured_GBs"] = roofline["traffic"] / 1e9 / (kernels[dominant]["avg_ms"] / 1e3)
+                        roofline["hbm_frac"] = roofline["hbm_measured_GBs"] / HBM_PEAK_GBS
+                    for f in ("valu_busy", "lanes_active", "valu_frac", "wait_frac", "l2_hit_rate", "vmem_latency_cycles"):
+                        if k.get(f) is not None:
+                            roofline[f] = k[f]
+                    # what bounds the kernel, from the data: the larger of the HBM fraction and the useful-lane
+                    # VALU fraction names the roof; a kernel whose waves wait most of their cycles with neither
+                    # near its roof is latency-bound
+                    hf, vf, wf = roofline.get("hbm_frac") or 0.0, k.get("valu_busy") or 0.0, k.get("wait_frac") or 0.0
+                    roofline["bound"] = "hbm" if hf >= max(vf, 0.5) else ("valu" if vf >= 0.6 or vf > wf else "latency")
+            except Exception as e:  # a malformed summary must not cost the bench line
+                roofline["pmc_error"] = str(e)
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            ncores = os.cpu_count() or 1
-            pcpu = make_params(W, H, B, args.cpu_spp, seed=0x52505447)
+            ncores, raw = host_cpus()
+            L, how = O.baseline_lib(native=True)
+            fast = O.OracleScene(scene, L)
+            # calibrate on 1 spp of 1/8 of the frame, then size the sample for ~15 s of wall time
+            pcal = make_params(W, H, B, 1, seed=0x52505447, tile=(32, 8), part=(0, 8))
             t1 = time.perf_counter()
-            osc.render(camera, pcpu, threads=ncores)
+            fast.render(camera, pcal, threads=ncores)
+            rate = (W * H / 8.0) / max(1e-6, time.perf_counter() - t1)
+            cpu_spp = args.cpu_spp or int(min(64, max(1, round(rate * 15.0 / (W * H)))))
+            pcpu = make_params(W, H, B, cpu_spp, seed=0x52505447)
+            t1 = time.perf_counter()
+            fast.render(camera, pcpu, threads=ncores)
             dt = time.perf_counter() - t1
-            cpu = {"value": W * H * args.cpu_spp / dt / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
-                   "sample": "%s %dx%d, %d bounces, %d spp (%.1f s wall): C++ restatement of rpt's rayon path "
-                             "(oracle/, one task per row over %d std::threads)" % (args.scene, W, H, B, args.cpu_spp, dt, ncores)}
+            # the instrumented checker build on a quarter of that sample, for the record
+            pins = make_params(W, H, B, max(1, cpu_spp // 4), seed=0x52505447)
+            t1 = time.perf_counter()
+            osc.render(camera, pins, threads=ncores)
+            dti = time.perf_counter() - t1
+            cpu = {"value": W * H * cpu_spp / dt / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
+                   "sample": "%s %dx%d, %d bounces, %d spp (%.1f s wall): C++ restatement of rpt's rayon path (oracle/, %s), one task "
+                             "per row claimed dynamically by %d std::threads on %s (%d logical CPUs)"
+                             % (args.scene, W, H, B, cpu_spp, dt, how, ncores, cpu_model(), raw),
+                   "instrumented_checker_build": {"value": W * H * pins.iterations / dti / 1e6, "unit": "Msamples/s",
+                                                  "note": "liboracle.so with visit counters compiled in (x86-64-v3)"}}
 
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -192,9 +275,14 @@ def main():
             "config": {"workload": "%s %dx%d, %d bounces, %d spp per step (BASELINE configs[1]: examples/cornell.rs)"
                                    % (args.scene, W, H, B, spp) if args.scene == "cornell" else
                                    "%s %dx%d, %d bounces, %d spp per step" % (args.scene, W, H, B, spp),
-                       "precision_mode": args.mode, "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")), "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
+                       "precision_mode": args.mode,
+                       "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")),
+                       "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
                        "collective": "RCCL reduce(sum) of the f32 framebuffer to rank 0" if world > 1 else "none",
-                       "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1)},
+                       "timed_region": "render + reduce + D2H of the f32 frame to pinned host memory on rank 0",
+                       "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1),
+                       "scene_create_ms": scene_create_ms,
+                       "wall_clock_per_frame_ms": scene_create_ms + elapsed / args.steps * 1e3},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -207,6 +207,10 @@ enum {
   RPT_K_SHADOW = 3, /* shadow-ray traversal                      */
   RPT_K_RESOLVE = 4,/* nested firefly-clamp fold + accumulation  */
   RPT_K_PATHS = 5,  /* persistent path kernel: all of the above in registers */
+  RPT_K_TREE_TRACE = 6, /* per-tree persistent kd traversal (closest-hit and shadow queries of deep trees);
+                           its time is also part of RPT_K_EXTEND / RPT_K_SHADOW, which bracket whole queries */
+  RPT_K_TREE_SORT = 7,  /* root slab test + queue append (rpt_tree_enter) and the ray sort in front of a traversal;
+                           likewise contained in RPT_K_EXTEND / RPT_K_SHADOW */
   RPT_K_COUNT = 8
 };
 

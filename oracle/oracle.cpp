@@ -19,7 +19,7 @@
 // exp/ln/atan/sin_cos/acos/atan2: the reference calls the platform libm through Rust's std.
 // Default build: the fdlibm restatement of include/rpt_math.h (pure IEEE arithmetic, so the
 // gfx950 kernels reproduce it bit for bit).  -DORACLE_SYSTEM_LIBM: the host's glibc instead
-// (liboracle_sysm.so) — tests/test_oracle_libm.py shows the two builds agree.
+// (liboracle_sysm.so) — tests/test_rpt_math.py shows the two builds agree.
 #include "../include/rpt_math.h"
 
 #include <algorithm>
@@ -121,6 +121,12 @@ struct Counters : OracleCounters {
 };
 thread_local Counters* tl_cnt = nullptr;
 thread_local bool tl_shadow = false; // geometry visited on behalf of a shadow ray (renderer.rs:191)
+#ifdef ORACLE_NO_COUNTERS
+// the CPU-baseline builds (liboracle_fast.so, liboracle_native.so): no visit counting in the hot loops, which is
+// what the reference's own binary looks like; counters requested from such a build read zero
+#define COUNT(field) do { } while (0)
+#define COUNT_GEO(field) do { } while (0)
+#else
 #define COUNT(field)            \
   do {                          \
     if (tl_cnt) tl_cnt->field++; \
@@ -133,6 +139,7 @@ thread_local bool tl_shadow = false; // geometry visited on behalf of a shadow r
       else tl_cnt->field++;                                \
     }                                                      \
   } while (0)
+#endif
 
 // ------------------------------------------------------------------ RNG
 // Philox4x32-10 (Salmon et al., SC'11), the Random123 reference constants.

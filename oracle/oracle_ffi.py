@@ -35,17 +35,39 @@ def build():
     subprocess.check_call(["make", "-s", "-C", HERE])
 
 
+def _load(path):
+    L = C.CDLL(path)
+    L.oracle_rng_u64.restype = C.c_uint64
+    L.oracle_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
+    L.oracle_buffer_variance.restype = C.c_double
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
-        L = C.CDLL(LIB_PATH)
-        L.oracle_rng_u64.restype = C.c_uint64
-        L.oracle_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
-        L.oracle_buffer_variance.restype = C.c_double
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def baseline_lib(native=True, timeout=180):
+    """The CPU-baseline build of the same restatement: no visit counters in the hot loops.  With
+    native=True it is compiled here and now with -march=native for THIS host (oracle/Makefile target
+    `native`); if that is not possible the portable prebuilt liboracle_fast.so is used.
+    -> (CDLL, description)"""
+    if native:
+        try:
+            subprocess.check_call(["make", "-s", "-C", HERE, "native"], timeout=timeout,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return _load(os.path.join(HERE, "liboracle_native.so")), "g++ -O3 -march=native -ffp-contract=off, no counters"
+        except Exception:
+            pass
+    path = os.path.join(HERE, "liboracle_fast.so")
+    if not os.path.exists(path):
+        build()
+    return _load(path), "g++ -O3 -march=x86-64-v3 -ffp-contract=off, no counters"
 
 
 def _dp(a):
@@ -57,10 +79,11 @@ def _v3(v):
 
 
 class OracleScene:
-    def __init__(self, scene):
+    def __init__(self, scene, L=None):
+        self.L = L or lib()
         self.desc, self.keep = scene.lower()
         h = C.c_void_p()
-        rc = lib().oracle_scene_create(C.byref(self.desc), C.byref(h))
+        rc = self.L.oracle_scene_create(C.byref(self.desc), C.byref(h))
         if rc != 0:
             raise _abi.RptGpuError(rc, "oracle_scene_create")
         self.h = h
@@ -68,7 +91,7 @@ class OracleScene:
     def __del__(self):
         try:
             if self.h:
-                lib().oracle_scene_destroy(self.h)
+                self.L.oracle_scene_destroy(self.h)
                 self.h = None
         except Exception:
             pass
@@ -77,7 +100,7 @@ class OracleScene:
         out = np.empty((params.height * params.width, 3), dtype=np.float64)
         cam = camera.lower()
         cnt = OracleCounters()
-        rc = lib().oracle_render(self.h, C.byref(cam), C.byref(params), int(threads), _dp(out),
+        rc = self.L.oracle_render(self.h, C.byref(cam), C.byref(params), int(threads), _dp(out),
                                  C.byref(cnt) if counters else None)
         assert rc == 0
         return (out, cnt.as_dict()) if counters else out
@@ -87,7 +110,7 @@ class OracleScene:
         rgb = np.zeros(3)
         rec = np.zeros((params.max_bounces + 1, 8))
         nrec = C.c_int(0)
-        rc = lib().oracle_trace_sample(self.h, C.byref(cam), C.byref(params), C.c_uint32(x), C.c_uint32(y),
+        rc = self.L.oracle_trace_sample(self.h, C.byref(cam), C.byref(params), C.c_uint32(x), C.c_uint32(y),
                                        C.c_uint64(sample), _dp(rgb), _dp(rec), C.byref(nrec))
         assert rc == 0
         return rgb, rec[:nrec.value]
@@ -100,7 +123,7 @@ class OracleScene:
         nrm = np.empty((n, 3))
         obj = np.empty(n, dtype=np.int32)
         cnt = OracleCounters()
-        rc = lib().oracle_closest_hit(self.h, C.c_uint64(n), _dp(o), _dp(d), _dp(t), _dp(nrm),
+        rc = self.L.oracle_closest_hit(self.h, C.c_uint64(n), _dp(o), _dp(d), _dp(t), _dp(nrm),
                                       obj.ctypes.data_as(C.POINTER(C.c_int32)),
                                       C.byref(cnt) if counters else None)
         assert rc == 0

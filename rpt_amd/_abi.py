@@ -30,7 +30,7 @@ RPT_FLAG_PROFILE_KERNELS = 1
 RPT_FLAG_WAVEFRONT = 2
 RPT_FLAG_GENERAL_TRAVERSAL = 4
 RPT_FLAG_PERSISTENT = 8
-RPT_K_RAYGEN, RPT_K_EXTEND, RPT_K_SHADE, RPT_K_SHADOW, RPT_K_RESOLVE, RPT_K_PATHS = range(6)
+RPT_K_RAYGEN, RPT_K_EXTEND, RPT_K_SHADE, RPT_K_SHADOW, RPT_K_RESOLVE, RPT_K_PATHS, RPT_K_TREE_TRACE, RPT_K_TREE_SORT = range(8)
 RPT_K_COUNT = 8
 
 f64 = C.c_double

@@ -33,9 +33,14 @@ struct HipError {
     if (_e != hipSuccess) throw HipError{_e, #expr, __LINE__}; \
   } while (0)
 
+// owning device allocation: released by the destructor, never copied
 template <class T> struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
   void alloc(size_t count) {
     if (count <= n && p) return;
     release();
@@ -118,13 +123,8 @@ struct rptgpu_scene {
   ~rptgpu_scene() {
     (void)hipSetDevice(device);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
-    insts.release(); trees.release(); nodes.release(); refs.release(); tris.release(); trix.release();
-    materials.release(); lights.release(); env_texels.release();
-    ray.release(); hit.release(); rec.release(); shadow.release(); accum.release(); out_full.release();
-    hit_obj.release(); draw.release(); queue_a.release(); queue_b.release(); counters.release();
-    pixels.release(); nrec.release(); prec.release(); pcounters.release();
-    tq.release(); tq_ctr.release(); srt.release();
     if (stream) (void)hipStreamDestroy(stream);
+    // every DevBuf member frees itself (its destructor runs after this body, on `device`)
   }
 };
 
@@ -178,6 +178,25 @@ struct Bracket {
     h->pending.push_back({kind, e0, e0 + 1});
   }
 };
+
+// launch_query's accounting hook: phases of a query bracketed with pool events like every other launch
+struct QueryMarks {
+  rptgpu_scene* h;
+  bool on;
+  Bracket* open[RPT_K_COUNT] = {};
+};
+void query_mark(void* ctx, int kind, int end) {
+  QueryMarks* q = (QueryMarks*)ctx;
+  if (kind < 0 || kind >= RPT_K_COUNT) return;
+  if (!end) {
+    delete q->open[kind];
+    q->open[kind] = new Bracket(q->h, kind, q->on);
+  } else if (q->open[kind]) {
+    q->open[kind]->done();
+    delete q->open[kind];
+    q->open[kind] = nullptr;
+  }
+}
 
 void drain_events(rptgpu_scene* h) {
   for (auto& p : h->pending) {
@@ -310,9 +329,11 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       uint32_t spp_l = n_launch ? (p->iterations + n_launch - 1) / n_launch : 0;
       uint32_t chunk = std::max(1u, std::min(h->paths_chunk, std::max(1u, spp_l)));
       uint64_t n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
-      if (n_items > 0xFFFFFFF0ull) { // 32-bit work counter
-        chunk = (uint32_t)(((uint64_t)spp_l * npix + 0xFFFFFFF0ull - 1) / 0xFFFFFFF0ull);
-        n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
+      // 32-bit work counter: every thread of the grid may fetch once past the end, so items + threads must fit
+      const uint64_t item_limit = 0xFFFFFFF0ull - (uint64_t)h->num_cus * 16 * 64;
+      if (n_items > item_limit) {
+        chunk = (uint32_t)(((uint64_t)spp_l * npix + item_limit - 1) / item_limit);
+        while ((n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk)) > item_limit) chunk++;
       }
       const bool flat = h->all_flat && !h->dscene.force_general;
       FlatLayout lay = h->flat_layout;
@@ -342,8 +363,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         fr.sample_base = p->sample_index_base + s0;
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
         { Bracket b(h, RPT_K_PATHS, prof);
-          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk, nblocks, flat ? &lay : nullptr,
-                    flat_lds);
+          kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk,
+                    (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, flat ? &lay : nullptr, flat_lds);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
       }
@@ -376,6 +397,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
       rptdev::Camera cam = make_camera(*camera);
       const bool any_lights = h->dscene.num_lights > 0;
+      QueryMarks qm{h, prof};
+      const QueryHook qhook{query_mark, &qm};
 
       for (uint32_t s0 = 0; s0 < p->iterations; s0 += s_chunk) {
         uint32_t sc = std::min(s_chunk, p->iterations - s0);
@@ -392,7 +415,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           { Bracket b(h, RPT_K_EXTEND, prof);
             if (by_object)
               kt->query(st, h->dscene, ps, queue, n_active, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
-                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr);
+                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook);
             else
               kt->extend(st, h->dscene, ps, queue, n_active);
             b.done(); }
@@ -406,7 +429,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
               for (int l = 0; l < h->dscene.num_lights; l++)
                 if (h->light_casts[l])
                   kt->query(st, h->dscene, ps, queue, n_active, l, h->srt.p, h->obj_deep.data(), h->obj_tris.data(),
-                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr);
+                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook);
               kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
             } else {
               kt->shadow(st, h->dscene, ps, queue, n_active, depth);
@@ -587,6 +610,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         lay.plane_cnt = cnt[0] | (cnt[1] << 4) | (cnt[2] << 8);
         lay.off_qtab = (uint32_t)off; off = up16(off + 12 * 64 * sizeof(double));
         h->plane_vals.upload(planes, h->stream);
+        HIP_TRY(hipStreamSynchronize(h->stream)); // `planes` dies with this block
         lay.plane_vals = h->plane_vals.p;
       }
       lay.off_rec = (uint32_t)off;
@@ -659,7 +683,6 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
     hipStream_t st = h->stream;
     DevBuf<double> d_o, d_d, d_t, d_n;
     DevBuf<int32_t> d_obj;
-    struct Guard { DevBuf<double>&a, &b, &c, &d; DevBuf<int32_t>& e; ~Guard() { a.release(); b.release(); c.release(); d.release(); e.release(); } } g{d_o, d_d, d_t, d_n, d_obj};
     d_o.alloc(3 * n); d_d.alloc(3 * n); d_t.alloc(n); d_n.alloc(3 * n); d_obj.alloc(n);
     HIP_TRY(hipMemcpyAsync(d_o.p, origins, 3 * n * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_d.p, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -936,6 +959,8 @@ const char* rptgpu_kernel_name(int k) {
     case RPT_K_SHADOW: return "rpt_shadow";
     case RPT_K_RESOLVE: return "rpt_resolve";
     case RPT_K_PATHS: return "rpt_paths";
+    case RPT_K_TREE_TRACE: return "rpt_tree_trace";
+    case RPT_K_TREE_SORT: return "rpt_tree_enter+sort";
     default: return "";
   }
 }

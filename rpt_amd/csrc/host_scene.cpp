@@ -372,6 +372,19 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err) {
     rptdev::Material m;
     std::memset(&m, 0, sizeof(m));
     const RptMaterial& s = sc.objects[i].material;
+    { // sample_f's lobe probability (material.rs:233-235) goes to rng.gen_bool(f) (:264), which panics outside
+      // [0, 1] (NaN included); the device has no panic, so such a material is refused here
+      double f0 = (s.index - 1.0) / (s.index + 1.0);
+      f0 = f0 * f0;
+      double mean = ((s.color[0] + s.color[1]) + s.color[2]) / 3.0;
+      double f = (1.0 - s.metallic) * f0 + s.metallic * mean;
+      f = f * (1.0 - 0.2) + 1.0 * 0.2;
+      if (!(f >= 0.0 && f <= 1.0)) {
+        err = "material of object " + std::to_string(i) + ": specular lobe probability " + std::to_string(f) +
+              " is outside [0, 1] (gen_bool would panic, material.rs:264)";
+        return RPTGPU_E_INVALID_ARGUMENT;
+      }
+    }
     std::memcpy(m.color, s.color, sizeof(m.color));
     m.index = s.index; m.roughness = s.roughness; m.metallic = s.metallic;
     m.emittance = s.emittance; m.transparent = s.transparent ? 1 : 0;

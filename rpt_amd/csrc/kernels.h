@@ -29,6 +29,13 @@ struct SortBufs {
   size_t tmp_bytes;
 };
 
+// accounting hook of launch_query: called with (ctx, kind, 0) before and (ctx, kind, 1) after the launches of
+// a phase of the query (kind = RPT_K_TREE_TRACE / RPT_K_TREE_SORT); may be null
+struct QueryHook {
+  void (*mark)(void* ctx, int kind, int end);
+  void* ctx;
+};
+
 struct KernelTable {
   void (*raygen)(hipStream_t, const rptdev::Frame&, const rptdev::Camera&, const rptdev::PathState&, uint32_t n_paths);
   void (*extend)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n);
@@ -45,14 +52,14 @@ struct KernelTable {
   int (*paths_max_blocks_per_cu)(bool flat, uint32_t flat_lds_bytes);
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
-                uint32_t chunk, uint32_t nblocks, const FlatLayout* flat, uint32_t flat_lds_bytes);
+                uint32_t chunk, uint32_t n_items, uint32_t nblocks, const FlatLayout* flat, uint32_t flat_lds_bytes);
   // pixel sums of a launch's samples, in sample order
   void (*sum_samples)(hipStream_t, const rptdev::Frame&, const double* lbuf, uint32_t spp, bool first);
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run
   // object by object with per-tree ray compaction and persistent traversal
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                 int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
-                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort);
+                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook);
   size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);

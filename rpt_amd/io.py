@@ -29,6 +29,15 @@ def _parse_index(value, length):  # io.rs:10-18
     return index - 1 if index > 0 else length + index
 
 
+def _at(seq, idx):
+    """seq[idx] as the reference indexes a Vec: a negative result of parse_index wraps to a huge usize there
+    and the access panics (io.rs:14-16, 185-196); Python's negative indexing would silently pick an element
+    from the end instead."""
+    if not 0 <= idx < len(seq):
+        raise IndexError("index out of bounds: the len is %d but the index is %d" % (len(seq), idx))
+    return seq[idx]
+
+
 def _point(tokens):  # parse_obj_point io.rs:150-161
     try:
         return (float(tokens[1]), float(tokens[2]), float(tokens[3]))
@@ -48,11 +57,11 @@ def _face(tokens, vertices, normals):  # parse_obj_face io.rs:163-200
     tris = []
     for i in range(1, len(vi) - 1):
         a, b, c = 0, i, i + 1
-        v1, v2, v3 = vertices[vi[a]], vertices[vi[b]], vertices[vi[c]]
+        v1, v2, v3 = _at(vertices, vi[a]), _at(vertices, vi[b]), _at(vertices, vi[c])
         if vni[a] is None or vni[b] is None or vni[c] is None:
             tris.append(Triangle.from_vertices(v1, v2, v3))
         else:
-            tris.append(Triangle(v1, v2, v3, normals[vni[a]], normals[vni[b]], normals[vni[c]]))
+            tris.append(Triangle(v1, v2, v3, _at(normals, vni[a]), _at(normals, vni[b]), _at(normals, vni[c])))
     return tris
 
 

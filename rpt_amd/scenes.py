@@ -371,6 +371,38 @@ def compound():
     return scene, camera, dict(width=1024, height=1024, max_bounces=5, num_samples=50)
 
 
-SCENES = {"sphere": sphere_scene, "cornell": cornell, "dragon": dragon,
+# ----------------------------------------------------------------------------- a flat scene that is not Cornell
+def polygon_room(n_walls=23, transformed_every=0, sides=(4, 5, 6, 8), seed=3):
+    """Many small polygon meshes in a row (single-leaf trees), optionally with a Transformed one every few
+    objects and a cube / sphere in between: the shapes the flat path kernel batches or must not batch."""
+    rs = np.random.RandomState(seed)
+    scene = Scene()
+    for i in range(n_walls):
+        k = sides[i % len(sides)]
+        c = rs.uniform(-2.0, 2.0, 3)
+        a = rs.randn(3)
+        a /= np.linalg.norm(a)
+        b = np.cross(a, rs.randn(3))
+        b /= np.linalg.norm(b)
+        r = rs.uniform(0.5, 1.5)
+        verts = [tuple(c + r * (math.cos(t) * a + math.sin(t) * b)) for t in np.linspace(0, 2 * math.pi, k, endpoint=False)]
+        shape = polygon(verts)
+        if transformed_every and i % transformed_every == transformed_every - 1:
+            shape = shape.rotate_y(0.3 * i).translate((0.1 * i, 0.0, -0.05 * i))
+        mat = Material.diffuse(tuple(rs.uniform(0.3, 0.9, 3))) if i % 3 else Material.specular(tuple(rs.uniform(0.3, 0.9, 3)), 0.2)
+        scene.add(Object(shape).material(mat))
+        if i % 7 == 3:
+            scene.add(Object(cube().scale((0.4, 0.4, 0.4)).translate(tuple(rs.uniform(-1.5, 1.5, 3))))
+                      .material(Material.diffuse((0.8, 0.8, 0.8))))
+        if i % 7 == 5:
+            scene.add(Object(sphere().scale((0.3, 0.3, 0.3)).translate(tuple(rs.uniform(-1.5, 1.5, 3)))))
+    quad = polygon([(-0.5, 2.9, -0.5), (-0.5, 2.9, 0.5), (0.5, 2.9, 0.5), (0.5, 2.9, -0.5)])
+    scene.add(Light.Object(Object(quad).material(Material.light((1.0, 1.0, 0.9), 30.0))))
+    scene.add(Light.Point((20.0, 20.0, 20.0), (0.0, 0.0, 4.0)))
+    cam = Camera.look_at((0.0, 0.5, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.9)
+    return scene, cam, dict(width=1920, height=1080, max_bounces=8, num_samples=512)
+
+
+SCENES = {"room23": polygon_room, "sphere": sphere_scene, "cornell": cornell, "dragon": dragon,
           "fractal_spheres": fractal_spheres, "glass": glass, "wine_glass": wine_glass,
           "fractal_teapots": fractal_teapots, "basic": basic, "monomial_glass": monomial_glass, "spheres": spheres, "compound": compound}

@@ -1,26 +1,27 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py on the GPU box.  Usage (through gpurun, from the repo root):
-#   bash scripts/profile.sh r01            -> gpurun_out/prof_r01/...
-# Pass 1: kernel trace + stats of the bench command.  Passes 2-4: PMC counters, one pass each
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with sys/hip/hsa tracing).
+#   bash scripts/profile.sh <tag> <scene> <trace_spp|0> <pmc_spp> ["extra bench args"]
+#   e.g. bash scripts/profile.sh r02 cornell 0 512      -> gpurun_out/prof_r02_cornell/...
+# Pass 1: kernel trace + stats of the bench command (trace_spp = 0: the scene's DEFAULT bench line, so the kernel's
+# average duration in the stats equals the one bench.py reports).  Passes 2-4: PMC counters, each in its own run with
+# --kernel-trace only (never combined with sys/hip/hsa tracing); FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set -u
-TAG=${1:-r01}
-SPP=${2:-32}
-EXTRA="${3:-}"
+TAG=${1:-r02}
+SCENE=${2:-cornell}
+SPP=${3:-0}
+PSPP=${4:-4}
+EXTRA="${5:-}"
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/prof_$TAG
+OUT=$REPO/gpurun_out/prof_${TAG}_${SCENE}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# pass 1: the bench command itself.  With no extra args this is the DEFAULT bench line
-# (`python bench.py`: C2 at 512 spp, 3 steps + 1 warmup), so the kernel's average duration in the
-# stats equals the one bench.py reports; SPP > 0 profiles a shorter variant instead.
-if [ "$SPP" = "0" ]; then CMD="python $REPO/bench.py $EXTRA"; else CMD="python $REPO/bench.py --steps 2 --warmup 1 --spp $SPP --no-cpu-baseline $EXTRA"; fi
+if [ "$SPP" = "0" ]; then CMD="python $REPO/bench.py --scene $SCENE $EXTRA"; else CMD="python $REPO/bench.py --scene $SCENE --steps 2 --warmup 1 --spp $SPP --no-cpu-baseline $EXTRA"; fi
 echo "$CMD" > $OUT/trace_command.txt
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
-PCMD="python $REPO/bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline $EXTRA"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- $PCMD > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o bench -- $PCMD > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_sq -o bench -- $PCMD > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o bench -- $PCMD > $OUT/pmc_tcc.log 2>&1
-find $OUT -name '*.csv' | head -40
-tail -2 $OUT/bench_trace.log
+PCMD="python $REPO/bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline $EXTRA"
+echo "$PCMD" > $OUT/pmc_command.txt
+rocprofv3 --pmc FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d $OUT/pmc_a -o bench -- $PCMD > $OUT/pmc_a.log 2>&1
+rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM --kernel-trace -d $OUT/pmc_b -o bench -- $PCMD > $OUT/pmc_b.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_c -o bench -- $PCMD > $OUT/pmc_c.log 2>&1
+find $OUT -name '*.db' | head -10
+grep -h '^{' $OUT/bench_trace.log | tail -1 | cut -c1-400

@@ -1,33 +1,37 @@
 #!/usr/bin/env python
-"""Turns the rocprofv3 (rocpd sqlite) outputs of scripts/profile.sh into the committed summaries
-under profiles/:  <tag>_kernel_stats.csv (= rocprofv3 --stats top-kernels), <tag>_pmc.csv (per-kernel
-counter sums and per-launch means), <tag>_traffic.json (HBM bytes per launch, FETCH_SIZE doubled as
-MI355X_MICROARCH.md prescribes for gfx950), <tag>_summary.md.
+"""Turns the rocprofv3 (rocpd sqlite) outputs of scripts/profile.sh into the committed summaries under profiles/:
+<tag>_<scene>_kernel_stats.csv (= rocprofv3 --stats top-kernels), <tag>_<scene>_pmc.csv (per-kernel counter sums and
+per-launch means), <tag>_<scene>_pmc.json (per kernel: HBM bytes per sample — FETCH_SIZE doubled as MI355X_MICROARCH.md
+prescribes for gfx950, WRITE_SIZE as reported —, VALU busy fraction, active lanes per VALU instruction, wait fraction,
+L2 hit rate; read by bench.py for the roofline object) and <tag>_<scene>_summary.md.
 
-    python scripts/summarize_profile.py r01
+    python scripts/summarize_profile.py r02 cornell
 """
 import csv
 import json
 import os
+import re
 import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+scene = sys.argv[2] if len(sys.argv) > 2 else "cornell"
+src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, scene))
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+pre = os.path.join(dst, "%s_%s" % (tag, scene))
+NUM_SIMD, NUM_SE = 1024, 32  # MI355X: 256 CUs x 4 SIMDs; 8 XCDs x 4 shader engines
 
 
 def short(name):
-    """'void rpt_strict::rpt_paths<rpt_strict::KdFlat>(rptdev::Scene, ...)' -> 'rpt_paths<KdFlat>';
-    the two builds of the persistent path kernel are reported under the bench line's name `rpt_paths`
-    (the variant is listed in the notes of profiles/README.md)."""
-    import re
+    """'void rpt_strict::rpt_paths<rpt_strict::KdFlat>(rptdev::Scene, ...)' -> 'rpt_paths'; template arguments are
+    dropped so that the names match bench.py's kernel kinds (the variants are listed in the summary's full names)."""
     head = name.split("(")[0]
     head = re.sub(r"\b\w+::", "", head).replace("void ", "").strip()
-    if head.startswith("rpt_paths<"):
-        return "rpt_paths"
+    for k in ("rpt_paths", "rpt_tree_trace", "rpt_tree_enter", "rpt_rays_init", "rpt_rays_objects"):
+        if head.startswith(k + "<"):
+            return k
     return head
 
 
@@ -36,31 +40,44 @@ def db(sub):
     return sqlite3.connect(p) if os.path.exists(p) else None
 
 
-rows = []
+def bench_line(log):
+    p = os.path.join(src, log)
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith("{") and '"ms_per_step"' in line:
+                try:
+                    return json.loads(line)
+                except Exception:
+                    pass
+    return None
+
+
+rows, regs = [], {}
 c = db("trace")
 if c:
     cur = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels")
     rows = [(short(n), n, calls, tot, avg, pct) for n, calls, tot, avg, pct in cur]
-    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
+    with open(pre + "_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "percent", "full_name"])
         for s, n, calls, tot, avg, pct in rows:
             w.writerow([s, calls, "%.3f" % tot, "%.3f" % avg, "%.2f" % pct, n])
-    regs = {}
-    for name, v, s, scr in c.execute("select name, max(vgpr_count), max(sgpr_count), max(scratch_size) from kernels group by name"):
-        regs[short(name)] = (v, s, scr)
+    for name, v, s, scr, lds in c.execute("select name, max(vgpr_count), max(sgpr_count), max(scratch_size), max(lds_size) from kernels group by name"):
+        regs[name] = (v, s, scr, lds)
 
 pmc = {}  # kernel -> counter -> (sum, launches)
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
+for sub in ("pmc_a", "pmc_b", "pmc_c"):
     c = db(sub)
     if not c:
         continue
     q = ("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection "
          "group by kernel_name, counter_name")
     for k, cn, total, n in c.execute(q):
-        pmc.setdefault(short(k), {})[cn] = (total, n)
+        d = pmc.setdefault(short(k), {})
+        t0, n0 = d.get(cn, (0.0, 0))
+        d[cn] = (t0 + total, n0 + n)
 
-with open(os.path.join(dst, tag + "_pmc.csv"), "w", newline="") as f:
+with open(pre + "_pmc.csv", "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "counter", "sum_over_launches", "launches", "mean_per_launch"])
     for k in sorted(pmc):
@@ -68,62 +85,83 @@ with open(os.path.join(dst, tag + "_pmc.csv"), "w", newline="") as f:
             total, n = pmc[k][cn]
             w.writerow([k, cn, "%.6g" % total, n, "%.6g" % (total / max(1, n))])
 
-traffic = {}
+bl = bench_line("pmc_a.log") or bench_line("pmc_b.log") or bench_line("pmc_c.log")
+samples = None
+if bl:
+    samples = bl["value"] * 1e6 * bl["ms_per_step"] / 1e3 * bl["steps"]
+pcmd = open(os.path.join(src, "pmc_command.txt")).read().strip() if os.path.exists(os.path.join(src, "pmc_command.txt")) else ""
+pcmd = " ".join(w.split("/")[-1] if w.endswith("bench.py") else w for w in pcmd.split())
+out = {"workload": (bl["config"]["workload"] if bl else "") + " [PMC passes: %s]" % pcmd, "samples": samples, "kernels": {},
+       "_note": "FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE (KiB) as "
+                "reported (uncalibrated); valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * SQ_BUSY_CYCLES/32 SEs); lanes_active = "
+                "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64); valu_frac = valu_busy * lanes_active / 64; wait_frac = "
+                "SQ_WAIT_ANY / SQ_WAVE_CYCLES; vmem_latency_cycles = SQ_INST_LEVEL_VMEM / (SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR)"}
 for k, d in pmc.items():
     if not k.startswith("rpt_"):
         continue
-    t = {}
-    if "FETCH_SIZE" in d:  # KiB; gfx950 reports half the bytes of wide coalesced reads -> double
-        t["fetch_bytes_per_launch_raw"] = d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1] * 1024
-        t["fetch_bytes_per_launch_x2"] = 2 * t["fetch_bytes_per_launch_raw"]
-    if "WRITE_SIZE" in d:
-        t["write_bytes_per_launch"] = d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1] * 1024
-    if "fetch_bytes_per_launch_x2" in t and "write_bytes_per_launch" in t:
-        t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch_x2"] + t["write_bytes_per_launch"]
-    if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
-        h, m = d["TCC_HIT_sum"][0], d["TCC_MISS_sum"][0]
-        t["l2_hit_rate"] = h / max(1.0, h + m)
-    traffic[k] = t
-# the PMC passes render 4 spp at 1920x1080 in ONE rpt_paths launch: per-sample figures let bench.py
-# scale the measured traffic to the launch size it actually times
-PMC_SAMPLES = 1920 * 1080 * 4
-for k, t in traffic.items():
-    if k == "rpt_paths" and "hbm_bytes_per_launch" in t:
-        t["pmc_samples_per_launch"] = PMC_SAMPLES
-        t["hbm_bytes_per_sample"] = t["hbm_bytes_per_launch"] / PMC_SAMPLES
-traffic["_note"] = ("PMC passes ran bench.py --steps 1 --warmup 0 --spp 4 (2 spp per pass, 9 depths); "
-                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); "
-                    "WRITE_SIZE uncalibrated")
-json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
+    g = lambda cn: d[cn][0] if cn in d else None  # noqa: E731
+    t = {"launches": max(v[1] for v in d.values())}
+    if g("FETCH_SIZE") is not None:
+        t["fetch_bytes_x2"] = 2 * g("FETCH_SIZE") * 1024
+    if g("WRITE_SIZE") is not None:
+        t["write_bytes"] = g("WRITE_SIZE") * 1024
+    if "fetch_bytes_x2" in t and "write_bytes" in t:
+        t["hbm_bytes"] = t["fetch_bytes_x2"] + t["write_bytes"]
+        if samples:
+            t["hbm_bytes_per_sample"] = t["hbm_bytes"] / samples
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
+        t["l2_hit_rate"] = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_BUSY_CYCLES"):
+        t["valu_busy"] = g("SQ_ACTIVE_INST_VALU") * 4 / (NUM_SIMD * g("SQ_BUSY_CYCLES") / NUM_SE)
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+        t["lanes_active"] = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
+    if "valu_busy" in t and "lanes_active" in t:
+        t["valu_frac"] = t["valu_busy"] * t["lanes_active"] / 64.0
+    if g("SQ_WAIT_ANY") is not None and g("SQ_WAVE_CYCLES"):
+        t["wait_frac"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+    if g("SQ_INST_LEVEL_VMEM") and (g("SQ_INSTS_VMEM_RD") or 0) + (g("SQ_INSTS_VMEM_WR") or 0) > 0:
+        t["vmem_latency_cycles"] = g("SQ_INST_LEVEL_VMEM") / ((g("SQ_INSTS_VMEM_RD") or 0) + (g("SQ_INSTS_VMEM_WR") or 0))
+    out["kernels"][k] = t
+# kernel durations inside the PMC runs (for measured GB/s of each kernel: bytes / its own time in THAT run)
+c = db("pmc_a")
+if c:
+    try:
+        for name, tot, n in c.execute("select name, total_duration, total_calls from top_kernels"):
+            k = short(name)
+            if k in out["kernels"]:
+                out["kernels"][k]["pmc_run_total_us"] = out["kernels"][k].get("pmc_run_total_us", 0.0) + tot
+    except Exception:
+        pass
+for k, t in out["kernels"].items():
+    if "hbm_bytes" in t and t.get("pmc_run_total_us"):
+        t["hbm_GBs_in_pmc_run"] = t["hbm_bytes"] / 1e9 / (t["pmc_run_total_us"] / 1e6)
+        t["hbm_frac_in_pmc_run"] = t["hbm_GBs_in_pmc_run"] / 8000.0
+json.dump(out, open(pre + "_pmc.json", "w"), indent=1)
 
-with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
-    f.write("# rocprofv3 summary %s\n\n" % tag)
+with open(pre + "_summary.md", "w") as f:
+    f.write("# rocprofv3 summary %s %s\n\n" % (tag, scene))
     cmdf = os.path.join(src, "trace_command.txt")
-    cmd = open(cmdf).read().strip().replace(ROOT + "/", "").replace("/root/repo/", "") if os.path.exists(cmdf) else "python bench.py --steps 2 --warmup 1 --spp 32 --no-cpu-baseline"
+    cmd = open(cmdf).read().strip() if os.path.exists(cmdf) else ""
     cmd = " ".join(w.split("/")[-1] if w.endswith("bench.py") else w for w in cmd.split())
-    f.write("Command: `rocprofv3 --kernel-trace --stats -- %s` (scripts/profile.sh); PMC passes: "
-            "`--pmc <counters> --kernel-trace -- python bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline`.\n\n" % cmd)
-    bl = os.path.join(src, "bench_trace.log")
-    if os.path.exists(bl):
-        for line in open(bl):
-            if line.startswith("{") and '"ms_per_step"' in line:
-                try:
-                    d = json.loads(line)
-                    k = d["roofline"]["kernel"]
-                    f.write("bench.py's own line from that run: value = %.1f %s, ms_per_step = %.1f, `%s` avg launch = %.3f ms "
-                            "(HIP events) — compare with the avg us column below.\n\n"
-                            % (d["value"], d["unit"], d["ms_per_step"], k, d["roofline"]["kernels"][k]["avg_ms"]))
-                except Exception:
-                    pass
-    f.write("| kernel | calls | total ms | avg us | % | VGPR | SGPR | scratch B/lane |\n|---|---|---|---|---|---|---|---|\n")
+    f.write("Trace: `rocprofv3 --kernel-trace --stats -- %s`; PMC passes (scripts/profile.sh): `--pmc <counters> --kernel-trace -- %s`.\n\n" % (cmd, pcmd))
+    d = bench_line("bench_trace.log")
+    if d:
+        k = d["roofline"]["kernel"]
+        f.write("bench.py's own line from the traced run: value = %.1f %s, ms_per_step = %.1f, `%s` avg launch = %.3f ms "
+                "(HIP events) — compare with the avg us column below.\n\n"
+                % (d["value"], d["unit"], d["ms_per_step"], k, d["roofline"]["kernels"][k]["avg_ms"]))
+        json.dump(d, open(pre + "_bench_line.json", "w"), indent=1)
+    f.write("| kernel | calls | total ms | avg us | % | VGPR | SGPR | scratch B/lane | LDS B |\n|---|---|---|---|---|---|---|---|---|\n")
     for s, n, calls, tot, avg, pct in rows:
-        v = regs.get(s, ("", "", ""))
-        f.write("| %s | %d | %.2f | %.1f | %.1f | %s | %s | %s |\n" % (s, calls, tot / 1e3, avg, pct, v[0], v[1], v[2]))
-    f.write("\n## PMC (mean per launch)\n\n| kernel | counter | mean per launch |\n|---|---|---|\n")
-    for k in sorted(pmc):
-        if k.startswith("rpt_"):
-            for cn in sorted(pmc[k]):
-                total, n = pmc[k][cn]
-                f.write("| %s | %s | %.4g |\n" % (k, cn, total / max(1, n)))
-    f.write("\n## HBM traffic per launch (bytes)\n\n```json\n%s\n```\n" % json.dumps(traffic, indent=1))
-print(open(os.path.join(dst, tag + "_summary.md")).read())
+        v = regs.get(n, ("", "", "", ""))
+        f.write("| %s | %d | %.2f | %.1f | %.1f | %s | %s | %s | %s |\n" % (re.sub(r"\b\w+::", "", n.split("(")[0]).replace("void ", ""), calls, tot / 1e3, avg, pct, v[0], v[1], v[2], v[3]))
+    f.write("\n## Derived per kernel (PMC runs)\n\n| kernel | launches | HBM B/sample | HBM GB/s | of 8 TB/s | VALU busy | lanes/64 | VALU x lanes | wait | L2 hit | VMEM latency |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+    fmt = lambda v, p="%.3g": (p % v) if v is not None else ""  # noqa: E731
+    for k in sorted(out["kernels"], key=lambda k: -out["kernels"][k].get("pmc_run_total_us", 0)):
+        t = out["kernels"][k]
+        f.write("| %s | %d | %s | %s | %s | %s | %s | %s | %s | %s | %s |\n" % (
+            k, t["launches"], fmt(t.get("hbm_bytes_per_sample")), fmt(t.get("hbm_GBs_in_pmc_run")), fmt(t.get("hbm_frac_in_pmc_run")),
+            fmt(t.get("valu_busy")), fmt(t.get("lanes_active")), fmt(t.get("valu_frac")), fmt(t.get("wait_frac")),
+            fmt(t.get("l2_hit_rate")), fmt(t.get("vmem_latency_cycles"))))
+    f.write("\n" + out["_note"] + "\n")
+print(open(pre + "_summary.md").read())

@@ -112,8 +112,17 @@ def small(name):
                                           sphere().scale((0.2, 0.2, 0.2)).translate((2.2, 2.5, 3.0))]))
                            .material(Material.light((1.0, 0.9, 0.8), 25.0))))
         return s, c, make_params(64, 48, 3, 4, seed=113)
+    # the same scenes at 256x144 with 32 spp: ~10^6 samples each, so that draw sequences a 64x36 frame at 4 spp
+    # hardly ever produces (long rejection loops, TIR, gen_range redraws, deep clamp chains) do occur
+    if name == "cornell_hi":
+        s, c, d = scenes.cornell()
+        return s, c, make_params(256, 144, 8, 32, seed=202)
+    if name == "coverage_hi":
+        s, c = coverage()
+        return s, c, make_params(256, 144, 5, 32, seed=207, exposure_value=0.5)
     raise KeyError(name)
 
 
+HI_NAMES = ["cornell_hi", "coverage_hi"]
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
          "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots"]

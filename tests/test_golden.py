@@ -28,6 +28,15 @@ def test_oracle_reproduces_golden(oracle, name):
     assert np.isfinite(img).all() and (img >= 0).all()
 
 
+@pytest.mark.parametrize("name", small_scenes.HI_NAMES)
+def test_oracle_reproduces_high_sample_golden(oracle, name):
+    # 256x144 at 32 spp (~10^6 samples per scene): image only
+    scene, cam, p = small_scenes.small(name)
+    img = oracle.OracleScene(scene).render(cam, p, threads=0)
+    ref = load(name)["image"]
+    assert (img == ref).all() and np.isfinite(img).all()
+
+
 def test_golden_covers_every_device_feature():
     z = {n: load(n) for n in small_scenes.NAMES}
     names = z["coverage"]["counter_names"].tolist()

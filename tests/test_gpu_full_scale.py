@@ -1,0 +1,93 @@
+"""Parity at BASELINE scale: configs[2], [3], [4] of BASELINE.json built in FULL — the 100 352-triangle
+mesh (examples/dragon.rs:30-71 role), the 937-sphere fractal at 3840x2160 (examples/fractal_spheres.rs:3-76),
+the 16k-triangle lathed glass under a 2048x1024 HDRI at 16 bounces and the glass spheres at 16 bounces
+(examples/wine_glass.rs:27-85, examples/glass.rs:27-50) — with the DEFAULT pipeline and the DEFAULT
+environment, so that whatever the library picks on its own at that size (per-tree queries, the ray sort in
+front of a tree larger than the L2s, several passes per depth, stack levels beyond the LDS part, B = 16)
+is what gets compared.  The oracle renders a 1/64 .. 1/256 interleaved-tile part of the frame (seconds);
+the GPU renders the whole frame AND the part; all three agree bit for bit on the part's pixels.  On top,
+10^5 secondary rays from surface points go through rptgpu_closest_hit against the oracle.
+
+Cost per sample does not depend on spp, so these run at 2 spp instead of 256 / 1024 / 4096.
+"""
+import numpy as np
+import pytest
+
+import rpt_amd
+from rpt_amd import GpuScene, _abi, make_params, scenes
+
+pytestmark = pytest.mark.gpu
+
+# name -> (scene factory, part count of the oracle's share, spp)
+FULL = {
+    "dragon": (scenes.dragon, 64, 2),                    # C3: 1920x1080, B=8, 100 352 triangles, depth-17 tree
+    "fractal_spheres": (scenes.fractal_spheres, 128, 2),  # C4: 3840x2160, B=8
+    "wine_glass": (scenes.wine_glass, 128, 2),            # C5 (mesh variant): 3840x2160, B=16
+    "glass": (scenes.glass, 256, 2),                      # C5 (sphere variant): 3840x2160, B=16
+}
+
+
+def _same(a, b):
+    return (a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_baseline_config_at_full_size_bit_equal_to_oracle(oracle, name, monkeypatch):
+    for k in ("RPTGPU_DEEP_DEPTH", "RPTGPU_SORT_RAYS", "RPTGPU_SORT_MIN_BYTES", "RPTGPU_TARGET_PATHS",
+              "RPTGPU_PATHS_CHUNK", "RPTGPU_LBUF_BYTES"):
+        monkeypatch.delenv(k, raising=False)  # default environment: the library's own choices
+    factory, parts, spp = FULL[name]
+    scene, cam, cfg = factory()
+    W, H, B = cfg["width"], cfg["height"], cfg["max_bounces"]
+    g = GpuScene(scene, 0)
+    osc = oracle.OracleScene(scene)
+    seed = 0xC0FFEE + len(name)
+    part = (parts // 3, parts)
+    # the oracle's share of the frame
+    pp = make_params(W, H, B, spp, seed=seed, tile=(32, 8), part=part)
+    ref = osc.render(cam, pp, threads=0)
+    sel = np.zeros(W * H, dtype=bool)
+    tiles_x = (W + 31) // 32
+    ys, xs = np.divmod(np.arange(W * H), W)
+    sel[((ys // 8) * tiles_x + xs // 32) % parts == part[0]] = True
+    assert sel.sum() >= W * H // parts // 2
+    # GPU: the same part ...
+    g.reset_stats()
+    img_part = g.render_batch(cam, make_params(W, H, B, spp, seed=seed, tile=(32, 8), part=part,
+                                                flags=_abi.RPT_FLAG_PROFILE_KERNELS))
+    assert _same(img_part, ref).all(), (name, "part", np.abs(img_part - ref).max(), (~_same(img_part, ref)).any(axis=1).sum())
+    # ... and the WHOLE frame at full size (queues, sorts and passes at their real sizes)
+    full = g.render_batch(cam, make_params(W, H, B, spp, seed=seed, flags=_abi.RPT_FLAG_PROFILE_KERNELS))
+    assert np.isfinite(full).all() and (full >= 0).all()
+    assert _same(full[sel], ref[sel]).all(), (name, "full", (~_same(full[sel], ref[sel])).any(axis=1).sum())
+    assert (ref[~sel] == 0).all()
+    st = g.stats()
+    assert st.samples == sel.sum() * spp + W * H * spp
+    if name in ("dragon", "wine_glass", "fractal_spheres"):
+        assert st.kernel_launches[_abi.RPT_K_EXTEND] > 0  # deep trees -> the wavefront pipeline was chosen
+    # the persistent pipeline on the part as well (its traversal keeps 12 stack levels in LDS, the rest in scratch)
+    img_p = g.render_batch(cam, make_params(W, H, B, spp, seed=seed, tile=(32, 8), part=part, flags=_abi.RPT_FLAG_PERSISTENT))
+    assert _same(img_p, ref).all(), (name, "persistent")
+
+    # 10^5 secondary rays: from first-hit points into random directions (what bounce and shadow rays are)
+    rs = np.random.RandomState(len(name))
+    pix = rs.choice(np.flatnonzero(sel), 4000, replace=False)
+    o0 = np.empty((len(pix), 3))
+    d0 = np.empty((len(pix), 3))
+    for i, px in enumerate(pix):
+        o0[i], d0[i] = oracle.camera_ray(cam, pp, int(px % W), int(px // W), 0)
+    t0, n0, ob0 = osc.closest_hit(o0, d0)
+    t1, n1, ob1 = g.closest_hit(o0, d0)
+    assert _same(t0, t1).all() and (ob0 == ob1).all() and _same(n0, n1).all()
+    hit = ob0 >= 0
+    assert hit.sum() > 200, (name, hit.sum())
+    pos = o0[hit] + t0[hit, None] * d0[hit]
+    reps = -(-100000 // len(pos))
+    o = np.repeat(pos, reps, axis=0)[:100000]
+    d = rs.randn(len(o), 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0, n0, ob0 = osc.closest_hit(o, d)
+    t1, n1, ob1 = g.closest_hit(o, d)
+    bad = ~(_same(t0, t1) & (ob0 == ob1) & _same(n0, n1).all(axis=1))
+    assert not bad.any(), (name, int(bad.sum()), t0[bad][:4], t1[bad][:4])
+    g.close()

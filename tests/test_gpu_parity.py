@@ -157,6 +157,19 @@ def test_render_bit_equal_to_golden(built, name, pipeline):
     assert (img == ref).all(), "max |delta| = %g on %d pixels" % (np.abs(img - ref).max(), (img != ref).any(axis=1).sum())
 
 
+@pytest.mark.parametrize("pipeline", ["auto", "persistent", "wavefront"])
+@pytest.mark.parametrize("name", small_scenes.HI_NAMES)
+def test_high_sample_render_bit_equal_to_golden(name, pipeline):
+    # 256x144 at 32 spp: ~10^6 samples per scene, every one of them the oracle's bits
+    scene, cam, p = small_scenes.small(name)
+    g = GpuScene(scene, 0)
+    p = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=PIPELINES[pipeline])
+    img = g.render_batch(cam, p)
+    g.close()
+    ref = load(name)["image"]
+    assert (img == ref).all(), "max |delta| = %g on %d pixels" % (np.abs(img - ref).max(), (img != ref).any(axis=1).sum())
+
+
 @pytest.mark.parametrize("sort", ["0", "1"])
 @pytest.mark.parametrize("name", small_scenes.NAMES)
 def test_per_tree_queries_and_ray_sorting_do_not_change_the_image(name, sort, monkeypatch):
@@ -410,33 +423,7 @@ def test_edge_cases_match_the_oracle(oracle):
 
 
 def _polygon_room(n_walls, transformed_every=0, sides=(4, 5, 6, 8), seed=3):
-    """Many small polygon meshes in a row (single-leaf trees), optionally with a Transformed one every few
-    objects and a cube / sphere in between: the shapes the flat path kernel batches or must not batch."""
-    rs = np.random.RandomState(seed)
-    scene = rpt_amd.Scene()
-    for i in range(n_walls):
-        k = sides[i % len(sides)]
-        c = rs.uniform(-2.0, 2.0, 3)
-        a = rs.randn(3)
-        a /= np.linalg.norm(a)
-        b = np.cross(a, rs.randn(3))
-        b /= np.linalg.norm(b)
-        r = rs.uniform(0.5, 1.5)
-        verts = [tuple(c + r * (math.cos(t) * a + math.sin(t) * b)) for t in np.linspace(0, 2 * math.pi, k, endpoint=False)]
-        shape = rpt_amd.polygon(verts)
-        if transformed_every and i % transformed_every == transformed_every - 1:
-            shape = shape.rotate_y(0.3 * i).translate((0.1 * i, 0.0, -0.05 * i))
-        mat = rpt_amd.Material.diffuse(tuple(rs.uniform(0.3, 0.9, 3))) if i % 3 else rpt_amd.Material.specular(tuple(rs.uniform(0.3, 0.9, 3)), 0.2)
-        scene.add(rpt_amd.Object(shape).material(mat))
-        if i % 7 == 3:
-            scene.add(rpt_amd.Object(rpt_amd.cube().scale((0.4, 0.4, 0.4)).translate(tuple(rs.uniform(-1.5, 1.5, 3))))
-                      .material(rpt_amd.Material.diffuse((0.8, 0.8, 0.8))))
-        if i % 7 == 5:
-            scene.add(rpt_amd.Object(rpt_amd.sphere().scale((0.3, 0.3, 0.3)).translate(tuple(rs.uniform(-1.5, 1.5, 3)))))
-    quad = rpt_amd.polygon([(-0.5, 2.9, -0.5), (-0.5, 2.9, 0.5), (0.5, 2.9, 0.5), (0.5, 2.9, -0.5)])
-    scene.add(rpt_amd.Light.Object(rpt_amd.Object(quad).material(rpt_amd.Material.light((1.0, 1.0, 0.9), 30.0))))
-    scene.add(rpt_amd.Light.Point((20.0, 20.0, 20.0), (0.0, 0.0, 4.0)))
-    cam = rpt_amd.Camera.look_at((0.0, 0.5, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.9)
+    scene, cam, _ = scenes.polygon_room(n_walls, transformed_every, sides, seed)
     return scene, cam
 
 
@@ -515,6 +502,45 @@ def test_flat_scenes_exact_ties_and_coplanar_surfaces(oracle):
     assert ((n0.view(np.int64) == n1.view(np.int64)) | (np.isnan(n0) & np.isnan(n1))).all()
     assert (ob0 == 0).sum() > 0 and (ob0 == 1).sum() == 0   # the duplicate never wins a tie against the first
     g.close()
+
+
+def test_scene_destroy_releases_device_memory():
+    # every device allocation behind a handle (scene, workspace, per-sample radiance buffer, sort buffers) is
+    # returned by rptgpu_scene_destroy: create / render / destroy in a loop keeps free HBM where it was
+    import torch
+    scene, cam, _ = scenes.cornell()
+    mesh_scene, mesh_cam, _ = scenes.dragon(nu=96, nv=16)
+
+    def cycle(monkey_env=None):
+        for sc, cm, flags in ((scene, cam, _abi.RPT_FLAG_PERSISTENT), (mesh_scene, mesh_cam, _abi.RPT_FLAG_WAVEFRONT)):
+            g = GpuScene(sc, 0)
+            g.render_batch(cm, make_params(512, 288, 4, 16, seed=1, flags=flags))  # 56 MB of per-sample radiance
+            g.close()
+
+    os.environ["RPTGPU_DEEP_DEPTH"] = "1"
+    os.environ["RPTGPU_SORT_RAYS"] = "1"
+    try:
+        cycle()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for _ in range(6):
+            cycle()
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info(0)[0]
+    finally:
+        del os.environ["RPTGPU_DEEP_DEPTH"], os.environ["RPTGPU_SORT_RAYS"]
+    assert free0 - free1 < (32 << 20), "leaked %.1f MB over 6 create/render/destroy cycles" % ((free0 - free1) / 2 ** 20)
+
+
+def test_material_that_would_panic_gen_bool_is_rejected():
+    # sample_f hands f = mix(lerp(f0, mean(color), metallic), 1, 0.2) to rng.gen_bool, which panics outside [0, 1]
+    # (material.rs:233-235, 264); the device cannot panic, so scene_create refuses such a material
+    for mat in (rpt_amd.Material.metallic_((3.0, 3.0, 3.0), 0.1), rpt_amd.Material.metallic_((float("nan"), 0.5, 0.5), 0.1)):
+        s = rpt_amd.Scene()
+        s.add(rpt_amd.Object(rpt_amd.sphere()).material(mat))
+        with pytest.raises(rpt_amd.RptGpuError) as e:
+            GpuScene(s, 0)
+        assert e.value.code == _abi.RPTGPU_E_INVALID_ARGUMENT
 
 
 def test_too_deep_tree_is_rejected():

@@ -126,3 +126,20 @@ def test_kd_closest_hit_equals_brute_force(oracle):
     assert (t0 == t1).all()  # same triangle test, same t: bit-equal
     hit = ob0 >= 0
     assert (n0[hit] == n1[hit]).all(axis=1).mean() > 0.999  # exact ties may pick the other face
+
+
+def test_full_size_mesh_tree_is_the_reference_rule_tree(oracle):
+    """The product's kd builder on the full C3 mesh: node count, leaf references and depth are those of the
+    reference rule as SURVEY appendix A measured them for a 100k-triangle mesh class, and equal the
+    oracle's independent builder node by node."""
+    tris = scenes.knot_mesh()
+    assert tris.shape == (100352, 18)
+    lo = np.minimum(np.minimum(tris[:, 0:3], tris[:, 3:6]), tris[:, 6:9])
+    hi = np.maximum(np.maximum(tris[:, 0:3], tris[:, 3:6]), tris[:, 6:9])
+    boxes = np.ascontiguousarray(np.concatenate([lo, hi], axis=1))
+    a = kdtree_build(boxes, _abi.load_library(), "rptgpu")
+    b = kdtree_build(boxes, oracle.lib(), "oracle")
+    for k in ("split", "info", "a", "b", "refs"):
+        assert (a[k] == b[k]).all(), k
+    assert a["max_depth"] == b["max_depth"] >= 15
+    assert len(a["refs"]) > 4 * len(tris)  # straddlers go to both sides (kdtree.rs:270-281): ~5x duplication
