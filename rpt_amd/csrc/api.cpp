@@ -73,6 +73,7 @@ struct rptgpu_scene {
   DevBuf<uint32_t> refs;
   DevBuf<rptdev::Tri> tris;
   DevBuf<rptdev::TriX> trix;
+  DevBuf<rptdev::LeafBox> lbox;
   DevBuf<rptdev::Material> materials;
   DevBuf<rptdev::Light> lights;
   DevBuf<double> env_texels;
@@ -100,6 +101,7 @@ struct rptgpu_scene {
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
   bool has_deep = false;
+  int mesh_pairs = 0;              // RPTGPU_MESH_PAIRS: wave-cooperative leaves for deep meshes (measured slower, off)
   DevBuf<uint32_t> tq, tq_ctr;
   // optional ray sort in front of the per-tree traversal (RPTGPU_SORT_RAYS)
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
@@ -415,7 +417,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           { Bracket b(h, RPT_K_EXTEND, prof);
             if (by_object)
               kt->query(st, h->dscene, ps, queue, n_active, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
-                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook);
+                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, h->mesh_pairs);
             else
               kt->extend(st, h->dscene, ps, queue, n_active);
             b.done(); }
@@ -429,7 +431,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
               for (int l = 0; l < h->dscene.num_lights; l++)
                 if (h->light_casts[l])
                   kt->query(st, h->dscene, ps, queue, n_active, l, h->srt.p, h->obj_deep.data(), h->obj_tris.data(),
-                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook);
+                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, h->mesh_pairs);
               kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
             } else {
               kt->shadow(st, h->dscene, ps, queue, n_active, depth);
@@ -531,6 +533,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->prefer_wavefront = fs.max_tree_depth >= 3;
     uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
     if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RPTGPU_MESH_PAIRS")) h->mesh_pairs = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_RAYS")) h->sort_mode = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_MIN_BYTES")) h->sort_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
     for (int i = 0; i < fs.num_objects; i++) {
@@ -630,17 +633,20 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->refs.upload(fs.refs, h->stream);
     h->tris.upload(fs.tris, h->stream);
     h->trix.upload(fs.lrec, h->stream);
+    h->lbox.upload(fs.lbox, h->stream);
     h->materials.upload(fs.materials, h->stream);
     h->lights.upload(fs.lights, h->stream);
     h->env_texels.upload(fs.env_texels, h->stream);
     HIP_TRY(hipStreamSynchronize(h->stream));
     rptdev::Scene& d = h->dscene;
-    d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p; d.lrec = h->trix.p;
+    d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p; d.lrec = h->trix.p; d.lbox = h->lbox.p;
     d.materials = h->materials.p; d.lights = h->lights.p; d.env_texels = h->env_texels.p;
     std::memcpy(d.env_color, fs.env_color, sizeof d.env_color);
     d.env_width = fs.env_width; d.env_height = fs.env_height; d.env_kind = fs.env_kind;
     d.num_objects = fs.num_objects; d.num_lights = (int32_t)fs.lights.size();
     d.num_shadow_lights = fs.num_shadow_lights;
+    d.use_leaf_boxes = 1;
+    if (const char* e = std::getenv("RPTGPU_LEAF_BOXES")) d.use_leaf_boxes = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_LBUF_BYTES")) {
       long long v = std::atoll(e);
       if (v >= 24) h->lbuf_max_bytes = (uint64_t)v;

@@ -43,6 +43,15 @@ struct alignas(16) TriX {
   double d00, d01, d11, denom;
 };
 
+// Conservative bounding box of one leaf entry of a MESH tree, in leaf order like TriX: six 16-bit fixed-point
+// coordinates relative to the tree's bounds (Tree::qlo / qscale), minima rounded down and maxima rounded up by
+// one step more than needed.  16 B = ONE per-lane gather.  It is a FILTER in front of Triangle::intersect: a
+// ray that misses the box (in the window [t_min, record.time]) cannot be accepted by the exact test, so skipping
+// the exact test changes nothing (kernels/shapes.inc, leaf_box_pass).
+struct alignas(16) LeafBox {
+  uint32_t w[4]; // w0 = min.x | min.y << 16, w1 = min.z | max.x << 16, w2 = max.y | max.z << 16, w3 unused
+};
+
 // A placed shape: a top-level scene object, a light's shape, or a child of a GROUP tree.
 struct alignas(16) Inst {
   int32_t kind;     // RPT_SHAPE_*
@@ -75,6 +84,8 @@ struct alignas(16) Tree {
   uint32_t _pad;
   uint64_t sample_zone; // rand 0.8 UniformInt zone for Uniform::from(0..num_prims): u64::MAX - (2^64 - n) % n,
   uint64_t _pad2;       // precomputed because a 64-bit modulo costs ~200 device instructions per light sample
+  double qlo[3];        // MESH: origin and step of the LeafBox fixed-point grid (coordinate = qlo + q * qscale)
+  double qscale[3];
 };
 
 struct alignas(16) Material {
@@ -100,6 +111,7 @@ struct Scene {
   const uint32_t* refs;
   const Tri* tris;   // vertices + vertex normals (sampling, shading normals)
   const TriX* lrec;  // intersection-ready records in LEAF order: lrec[j] belongs to refs[j]
+  const LeafBox* lbox; // conservative boxes of the same entries (MESH trees), leaf order
   const Material* materials;
   const Light* lights;
   const double* env_texels; // HDRI: width*height*3
@@ -110,7 +122,7 @@ struct Scene {
   int32_t num_lights;
   int32_t num_shadow_lights; // lights that cast a shadow ray (non-ambient)
   int32_t force_general;     // tests: always take the general (box-carrying) traversal
-  int32_t _pad;
+  int32_t use_leaf_boxes;    // conservative box filter in front of Triangle::intersect (RPTGPU_LEAF_BOXES, default on)
 };
 
 // camera constants, precomputed on the host exactly as Camera::cast_ray derives them per call

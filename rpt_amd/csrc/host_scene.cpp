@@ -194,6 +194,41 @@ void fill_trix(const RptTriangle& t, rptdev::TriX& x) {
   x.denom = x.d00 * x.d11 - x.d01 * x.d01;
 }
 
+// Conservative 16-bit boxes of a mesh's leaf entries (device_types.h LeafBox).  Grid: 65533 steps across the
+// tree's bounds per axis; a minimum is rounded down and a maximum up, then both move one more step outwards, so
+// the decoded box contains the triangle's true box with a margin of at least (1 - 1e-12) steps on every side —
+// orders of magnitude more than the rounding of the decode and of the slab arithmetic on the device.  A triangle
+// whose barycentric system is ill-conditioned (sliver: rounding in mesh.rs:64-73 could accept a point that is not
+// near the triangle) or that has a non-finite vertex gets the whole grid, i.e. it is never filtered.
+void fill_leaf_boxes(FlatScene& fs, int tree, uint32_t tri_base, const std::vector<Box>& boxes) {
+  rptdev::Tree& t = fs.trees[tree];
+  for (int k = 0; k < 3; k++) {
+    double ext = t.bounds[3 + k] - t.bounds[k];
+    t.qlo[k] = t.bounds[k];
+    t.qscale[k] = (ext > 0.0 && std::isfinite(ext)) ? ext / 65533.0 : 1.0;
+  }
+  size_t nrefs = fs.refs.size() - t.ref_base;
+  fs.lbox.resize(fs.refs.size());
+  for (size_t j = 0; j < nrefs; j++) {
+    uint32_t tri = fs.refs[t.ref_base + j];
+    const Box& b = boxes[tri];
+    const rptdev::TriX& x = fs.trix[tri_base + tri];
+    uint32_t q[6];
+    bool full = !(x.denom > 1e-10 * (x.d00 * x.d11)) || !std::isfinite(x.denom); // sliver / degenerate / NaN
+    for (int k = 0; k < 3 && !full; k++) {
+      double a = std::floor((b.lo[k] - t.qlo[k]) / t.qscale[k]) - 1.0;
+      double c = std::ceil((b.hi[k] - t.qlo[k]) / t.qscale[k]) + 1.0;
+      if (!(a == a) || !(c == c)) { full = true; break; }
+      q[k] = (uint32_t)std::fmin(std::fmax(a, 0.0), 65535.0);
+      q[3 + k] = (uint32_t)std::fmin(std::fmax(c, 0.0), 65535.0);
+    }
+    if (full) { q[0] = q[1] = q[2] = 0; q[3] = q[4] = q[5] = 65535; }
+    rptdev::LeafBox lb;
+    lb.w[0] = q[0] | (q[1] << 16); lb.w[1] = q[2] | (q[3] << 16); lb.w[2] = q[4] | (q[5] << 16); lb.w[3] = full ? 1u : 0u;
+    fs.lbox[t.ref_base + j] = lb;
+  }
+}
+
 struct Flattener {
   FlatScene& fs;
   std::string& err;
@@ -306,6 +341,7 @@ struct Flattener {
             fs.lrec.resize(fs.refs.size());
             for (size_t j = 0; j < nrefs; j++) fs.lrec[t.ref_base + j] = fs.trix[base + fs.refs[t.ref_base + j]];
           }
+          fill_leaf_boxes(fs, tr, base, boxes);
           mesh_cache[key] = tr;
           in.tree = tr;
         }
@@ -425,6 +461,7 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err) {
     fs.insts.insert(fs.insts.end(), g.second.begin(), g.second.end());
   }
   fs.lrec.resize(fs.refs.size()); // GROUP trees own ref slots too (unused records)
+  fs.lbox.resize(fs.refs.size());
   fs.env_kind = sc.environment.kind;
   std::memcpy(fs.env_color, sc.environment.color, sizeof(fs.env_color));
   if (sc.environment.kind == RPT_ENV_HDRI) {

@@ -32,6 +32,7 @@ struct FlatScene {
   std::vector<rptdev::Tri> tris;
   std::vector<rptdev::TriX> trix; // by triangle index (host-side staging only)
   std::vector<rptdev::TriX> lrec; // by refs[] position: what the device reads
+  std::vector<rptdev::LeafBox> lbox; // by refs[] position: conservative boxes in front of the exact test
   std::vector<rptdev::Material> materials;
   std::vector<rptdev::Light> lights;
   std::vector<double> env_texels;
