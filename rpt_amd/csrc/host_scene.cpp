@@ -199,8 +199,10 @@ void fill_trix(const RptTriangle& t, rptdev::TriX& x) {
 // the decoded box contains the triangle's true box with a margin of at least (1 - 1e-12) steps on every side —
 // orders of magnitude more than the rounding of the decode and of the slab arithmetic on the device.  A triangle
 // whose barycentric system is ill-conditioned (sliver: rounding in mesh.rs:64-73 could accept a point that is not
-// near the triangle) or that has a non-finite vertex gets the whole grid, i.e. it is never filtered.
-void fill_leaf_boxes(FlatScene& fs, int tree, uint32_t tri_base, const std::vector<Box>& boxes) {
+// near the triangle) or that has a non-finite vertex gets the whole grid, i.e. it is never filtered.  GROUP trees get
+// the boxes of their children the same way (a child's hit point lies on the child, hence in its bounding box).
+void fill_leaf_boxes(FlatScene& fs, int tree, int64_t tri_base /* < 0: a GROUP tree, entries are placed shapes */,
+                     const std::vector<Box>& boxes) {
   rptdev::Tree& t = fs.trees[tree];
   for (int k = 0; k < 3; k++) {
     double ext = t.bounds[3 + k] - t.bounds[k];
@@ -212,9 +214,12 @@ void fill_leaf_boxes(FlatScene& fs, int tree, uint32_t tri_base, const std::vect
   for (size_t j = 0; j < nrefs; j++) {
     uint32_t tri = fs.refs[t.ref_base + j];
     const Box& b = boxes[tri];
-    const rptdev::TriX& x = fs.trix[tri_base + tri];
     uint32_t q[6];
-    bool full = !(x.denom > 1e-10 * (x.d00 * x.d11)) || !std::isfinite(x.denom); // sliver / degenerate / NaN
+    bool full = false;
+    if (tri_base >= 0) {
+      const rptdev::TriX& x = fs.trix[tri_base + tri];
+      full = !(x.denom > 1e-10 * (x.d00 * x.d11)) || !std::isfinite(x.denom); // sliver / degenerate / NaN
+    }
     for (int k = 0; k < 3 && !full; k++) {
       double a = std::floor((b.lo[k] - t.qlo[k]) / t.qscale[k]) - 1.0;
       double c = std::ceil((b.hi[k] - t.qlo[k]) / t.qscale[k]) + 1.0;
@@ -341,7 +346,7 @@ struct Flattener {
             fs.lrec.resize(fs.refs.size());
             for (size_t j = 0; j < nrefs; j++) fs.lrec[t.ref_base + j] = fs.trix[base + fs.refs[t.ref_base + j]];
           }
-          fill_leaf_boxes(fs, tr, base, boxes);
+          fill_leaf_boxes(fs, tr, (int64_t)base, boxes);
           mesh_cache[key] = tr;
           in.tree = tr;
         }
@@ -368,6 +373,9 @@ struct Flattener {
         uint32_t base = (uint32_t)fs.insts.size();
         int tr = add_tree(boxes, base);
         if (tr < 0) return RPTGPU_E_TREE_TOO_DEEP;
+        // the children's boxes (Sphere / Cube / Mesh bounds through Transformed::bounding_box, shape.rs:153-176) contain
+        // every point their intersect can return; the same filter as for triangles applies
+        fill_leaf_boxes(fs, tr, -1, boxes);
         group_children.push_back({tr, std::move(kids)});
         in.tree = tr;
         const rptdev::Tree& t = fs.trees[tr];
