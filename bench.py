@@ -138,17 +138,30 @@ def main():
     t_create = time.perf_counter()
     gpu = rpt_amd.GpuScene(scene, local_rank)  # flatten + kd build (reference rule) + upload
     scene_create_ms = (time.perf_counter() - t_create) * 1e3
-    frame = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
-    host_frame = torch.empty(W * H * 3, dtype=torch.float32).pin_memory() if rank == 0 else None
-    render_part = D.gpu_render_part(gpu, camera)
+    host_frame = torch.empty(W * H * 3, dtype=torch.float32).pin_memory()
+    host_np = host_frame.numpy()
+    # The collective lives in the library (rptgpu_comm_init / rptgpu_render_batch_reduce: ncclReduce on the library's
+    # stream, then D2H on rank 0), so no torch op sits in the timed path.  Only the gloo stand-in used by the tests
+    # (several ranks sharing one GPU, which RCCL refuses) goes through torch.distributed.
+    lib_collective = world == 1 or backend == "nccl"
+    if lib_collective and world > 1:
+        uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0, device=dev)
+        gpu.comm_init(rank, world, uid[0])
+    frame = None if lib_collective else torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
+    render_part = None if lib_collective else D.gpu_render_part(gpu, camera)
     step_no = [0]
 
     def step():
         p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=0 if args.fixed_samples else step_no[0] * spp,
                         precision=precision, flags=_abi.RPT_FLAG_PROFILE_KERNELS | pipe_flag)
-        D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
-        if rank == 0:  # Renderer::sample ends with the colours in host memory (renderer.rs:127-128)
-            host_frame.copy_(frame, non_blocking=False)
+        if lib_collective:
+            # Renderer::sample on every rank; ends with the colours in host memory on rank 0 (renderer.rs:127-128)
+            gpu.render_batch_reduce(camera, p, root=0, out=host_np)
+        else:
+            D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
+            if rank == 0:
+                host_frame.copy_(frame, non_blocking=False)
         step_no[0] += 1
 
     def fence():
@@ -278,7 +291,7 @@ def main():
                        "precision_mode": args.mode,
                        "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")),
                        "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
-                       "collective": "RCCL reduce(sum) of the f32 framebuffer to rank 0" if world > 1 else "none",
+                       "collective": ("ncclReduce(sum, f32 framebuffer) to rank 0 inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else "torch.distributed reduce (gloo stand-in)") if world > 1 else "none",
                        "timed_region": "render + reduce + D2H of the f32 frame to pinned host memory on rank 0",
                        "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1),
                        "scene_create_ms": scene_create_ms,

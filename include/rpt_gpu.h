@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPTGPU_ABI_VERSION 2
+#define RPTGPU_ABI_VERSION 3
 
 /* ---- error codes (replace the reference's panics: buffer.rs:26,33,89, plane.rs:35) ---- */
 enum {
@@ -40,7 +40,8 @@ enum {
   RPTGPU_E_HIP = -4,               /* a HIP call failed; see rptgpu_last_error_detail          */
   RPTGPU_E_OUT_OF_MEMORY = -5,
   RPTGPU_E_TREE_TOO_DEEP = -6,     /* kd-tree deeper than the device traversal stack           */
-  RPTGPU_E_UNIMPLEMENTED_SAMPLE = -7 /* Light::Object over a Plane: plane.rs:34-36 panics      */
+  RPTGPU_E_UNIMPLEMENTED_SAMPLE = -7, /* Light::Object over a Plane: plane.rs:34-36 panics     */
+  RPTGPU_E_COMM = -8               /* RCCL is not available or a collective failed             */
 };
 
 /* ---- Material: src/material.rs:8-26 ---- */
@@ -254,6 +255,27 @@ int rptgpu_render_batch(rptgpu_scene* h, const RptCamera* camera, const RptRende
 int rptgpu_render_batch_device(rptgpu_scene* h, const RptCamera* camera,
                                const RptRenderParams* params, void* d_out, int out_is_f32,
                                void* stream);
+
+/* ---- multi-GPU: one process per GPU, pixel tiles shard across the ranks, ONE collective per batch.
+ * The reference's rows are independent (renderer.rs:118-127); rank r renders the 32x8 tiles with
+ * tile_id % world == r and the full frame is the SUM of the ranks' frames (every pixel is non-zero on
+ * exactly one rank; random numbers are keyed by pixel and sample, so the frame does not depend on the
+ * partition).  The library owns the communicator: one RCCL communicator per handle on the handle's
+ * device and stream (librccl is opened on first use; without it these calls return RPTGPU_E_COMM).
+ *   rank 0:      rptgpu_comm_unique_id(id);  hand the 128 bytes to every rank (any side channel)
+ *   every rank:  rptgpu_comm_init(h, rank, world, id);
+ *   per batch:   rptgpu_render_batch_reduce(h, camera, params, root, out_rgb32_on_root)
+ * rptgpu_render_batch_reduce replaces the body of Renderer::sample on every rank: it renders this
+ * rank's tiles (params->tile_*, part_* are overridden: 32x8 tiles, part = rank of world), reduces the
+ * f32 frames to `root` with ncclReduce(sum) on the library's stream over xGMI, and on `root` writes the
+ * width*height*3 f32 means to host memory (out_rgb32 may be NULL on other ranks).  Synchronous.
+ * With no communicator attached (world = 1) it is a plain single-GPU render into out_rgb32. */
+#define RPTGPU_UNIQUE_ID_BYTES 128
+int rptgpu_comm_unique_id(uint8_t out_id[RPTGPU_UNIQUE_ID_BYTES]);
+int rptgpu_comm_init(rptgpu_scene* h, int rank, int world, const uint8_t id[RPTGPU_UNIQUE_ID_BYTES]);
+int rptgpu_comm_destroy(rptgpu_scene* h);
+int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params,
+                               int root, float* out_rgb32 /* width*height*3 f32, host, on root */);
 
 /* ---- the closest-hit kernel on its own: replaces Renderer::get_closest_hit
  * (renderer.rs:211-220) for a batch of rays (host arrays, n rays, xyz interleaved).

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPTGPU_LIB") or os.path.join(HERE, "lib", "librptgpu.so")  # RPTGPU_LIB: dev A/B builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 RPTGPU_OK = 0
 RPTGPU_E_INVALID_ARGUMENT = -1
@@ -21,6 +21,8 @@ RPTGPU_E_HIP = -4
 RPTGPU_E_OUT_OF_MEMORY = -5
 RPTGPU_E_TREE_TOO_DEEP = -6
 RPTGPU_E_UNIMPLEMENTED_SAMPLE = -7
+RPTGPU_E_COMM = -8
+RPTGPU_UNIQUE_ID_BYTES = 128
 
 RPT_SHAPE_SPHERE, RPT_SHAPE_PLANE, RPT_SHAPE_CUBE, RPT_SHAPE_MESH, RPT_SHAPE_GROUP, RPT_SHAPE_MONOMIAL = range(6)
 RPT_LIGHT_POINT, RPT_LIGHT_AMBIENT, RPT_LIGHT_DIRECTIONAL, RPT_LIGHT_OBJECT = range(4)
@@ -122,6 +124,11 @@ SYMBOLS = [
     ("rptgpu_render_batch", C.c_int, [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), _PD]),
     ("rptgpu_render_batch_device", C.c_int,
      [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), _VP, C.c_int, _VP]),
+    ("rptgpu_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
+    ("rptgpu_comm_init", C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    ("rptgpu_comm_destroy", C.c_int, [_VP]),
+    ("rptgpu_render_batch_reduce", C.c_int,
+     [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), C.c_int, C.POINTER(C.c_float)]),
     ("rptgpu_closest_hit", C.c_int,
      [_VP, C.c_uint64, _PD, _PD, C.c_uint32, _PD, _PD, C.POINTER(C.c_int32)]),
     ("rptgpu_eval_math", C.c_int, [_VP, C.c_int, C.c_uint64, _PD, _PD, _PD]),

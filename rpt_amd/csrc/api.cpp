@@ -2,6 +2,7 @@
 // gfx950 kernels, accounting.  No compute happens on the host; if there is no HIP device every
 // compute entry point returns RPTGPU_E_NO_DEVICE (there is no CPU fallback by design).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -59,6 +60,41 @@ template <class T> struct DevBuf {
 };
 
 constexpr int MAX_EVENT_PAIRS = 4096;
+
+// ---- RCCL, opened on first use (the library has no link-time dependency on it) -----------------------------
+// the handful of declarations of <rccl/rccl.h> that are used here
+struct RcclUniqueId { char internal[128]; };
+typedef void* RcclComm;
+struct Rccl {
+  void* so = nullptr;
+  int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+  int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(RcclComm) = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, int, RcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0; // ncclFloat32, ncclSum (rccl.h)
+Rccl& rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.so) break;
+  }
+  if (!r.so) { r.why = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return r; }
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.so, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.so, "ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
+  r.Reduce = (decltype(r.Reduce))dlsym(r.so, "ncclReduce");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Reduce;
+  if (!r.ok) r.why = "librccl.so lacks an expected symbol";
+  return r;
+}
 
 } // namespace
 
@@ -121,10 +157,15 @@ struct rptgpu_scene {
   std::vector<Pending> pending;
   int ev_used = 0;
   uint64_t target_paths = 4u << 20; // paths in flight per pass
+  // multi-GPU: the communicator of this handle (rptgpu_comm_init) and its frame buffers
+  RcclComm comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  DevBuf<float> frame32, frame32_sum;
 
   ~rptgpu_scene() {
     (void)hipSetDevice(device);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    if (comm && rccl().ok) (void)rccl().CommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
     // every DevBuf member frees itself (its destructor runs after this body, on `device`)
   }
@@ -485,6 +526,7 @@ const char* rptgpu_strerror(int code) {
     case RPTGPU_E_OUT_OF_MEMORY: return "out of memory";
     case RPTGPU_E_TREE_TOO_DEEP: return "kd-tree deeper than the device traversal stack";
     case RPTGPU_E_UNIMPLEMENTED_SAMPLE: return "Shape::sample is unimplemented for this shape (plane.rs:34-36)";
+    case RPTGPU_E_COMM: return "RCCL unavailable or collective failed";
     default: return "unknown error";
   }
 }
@@ -676,6 +718,79 @@ int rptgpu_render_batch_device(rptgpu_scene* h, const RptCamera* camera, const R
                                int out_is_f32, void* stream) {
   if (!d_out) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null d_out");
   return render_impl(h, camera, params, d_out, out_is_f32 != 0, nullptr, (hipStream_t)stream);
+}
+
+int rptgpu_comm_unique_id(uint8_t out_id[RPTGPU_UNIQUE_ID_BYTES]) {
+  if (!out_id) return RPTGPU_E_INVALID_ARGUMENT;
+  Rccl& r = rccl();
+  if (!r.ok) return fail(nullptr, RPTGPU_E_COMM, r.why);
+  RcclUniqueId id;
+  int rc = r.GetUniqueId(&id);
+  if (rc != 0) return fail(nullptr, RPTGPU_E_COMM, std::string("ncclGetUniqueId: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"));
+  static_assert(sizeof(id) == RPTGPU_UNIQUE_ID_BYTES, "unique id size");
+  std::memcpy(out_id, &id, sizeof id);
+  return RPTGPU_OK;
+}
+
+int rptgpu_comm_init(rptgpu_scene* h, int rank, int world, const uint8_t id[RPTGPU_UNIQUE_ID_BYTES]) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "bad rank / world / id");
+  Rccl& r = rccl();
+  if (!r.ok) return fail(h, RPTGPU_E_COMM, r.why);
+  if (h->comm) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "the handle already has a communicator");
+  if (hipSetDevice(h->device) != hipSuccess) return fail(h, RPTGPU_E_HIP, "hipSetDevice");
+  RcclUniqueId uid;
+  std::memcpy(&uid, id, sizeof uid);
+  RcclComm c = nullptr;
+  int rc = r.CommInitRank(&c, world, uid, rank);
+  if (rc != 0) return fail(h, RPTGPU_E_COMM, std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"));
+  h->comm = c; h->comm_rank = rank; h->comm_world = world;
+  return RPTGPU_OK;
+}
+
+int rptgpu_comm_destroy(rptgpu_scene* h) {
+  if (!h) return RPTGPU_E_INVALID_ARGUMENT;
+  if (h->comm && rccl().ok) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)rccl().CommDestroy(h->comm);
+  }
+  h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+  return RPTGPU_OK;
+}
+
+int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, int root,
+                               float* out_rgb32) {
+  if (!h || !camera || !params) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  const int world = h->comm ? h->comm_world : 1, rank = h->comm ? h->comm_rank : 0;
+  if (root < 0 || root >= world) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "root out of range");
+  if (rank == root && !out_rgb32) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null out_rgb32 on the root rank");
+  RptRenderParams p = *params;
+  p.tile_width = 32; p.tile_height = 8; p.part_index = (uint32_t)rank; p.part_count = (uint32_t)world;
+  const uint64_t n = (uint64_t)p.width * p.height * 3;
+  try {
+    HIP_TRY(hipSetDevice(h->device));
+    h->frame32.alloc(n);
+    if (world > 1 && rank == root) h->frame32_sum.alloc(n);
+  } catch (const HipError& e) {
+    return hip_fail(h, e);
+  }
+  // the render leaves this rank's frame (zeros outside its tiles) in frame32; nothing is copied to the host yet
+  int rc = render_impl(h, camera, &p, h->frame32.p, true, nullptr, nullptr);
+  if (rc != RPTGPU_OK) return rc;
+  try {
+    float* result = h->frame32.p;
+    if (world > 1) {
+      Rccl& r = rccl();
+      int nrc = r.Reduce(h->frame32.p, rank == root ? h->frame32_sum.p : nullptr, (size_t)n, RCCL_FLOAT32, RCCL_SUM, root, h->comm, h->stream);
+      if (nrc != 0) return fail(h, RPTGPU_E_COMM, std::string("ncclReduce: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "error"));
+      result = h->frame32_sum.p;
+    }
+    if (rank == root) HIP_TRY(hipMemcpyAsync(out_rgb32, result, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } catch (const HipError& e) {
+    return hip_fail(h, e);
+  }
+  return RPTGPU_OK;
 }
 
 int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const double* dirs,

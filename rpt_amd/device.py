@@ -66,6 +66,33 @@ class GpuScene:
                                                    C.c_void_p(stream or 0))
         _abi.check(code, self.handle)
 
+    # ---- multi-GPU: the library's own RCCL communicator (include/rpt_gpu.h) ----
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128-byte id every rank passes to comm_init (hand it over any side channel)"""
+        lib = _abi.load_library()
+        buf = (C.c_uint8 * _abi.RPTGPU_UNIQUE_ID_BYTES)()
+        _abi.check(lib.rptgpu_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        buf = (C.c_uint8 * _abi.RPTGPU_UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _abi.check(self.lib.rptgpu_comm_init(self.handle, int(rank), int(world), buf), self.handle)
+
+    def comm_destroy(self):
+        _abi.check(self.lib.rptgpu_comm_destroy(self.handle), self.handle)
+
+    def render_batch_reduce(self, camera, params, root=0, out=None):
+        """Renderer::sample on every rank: this rank's tiles, ncclReduce(sum) of the f32 frames to `root`,
+        result in host memory on root.  `out`: float32 array of width*height*3 (allocated if None on root)."""
+        cam = camera.lower() if hasattr(camera, "lower") else camera
+        if out is None:
+            out = np.empty(params.height * params.width * 3, dtype=np.float32)
+        code = self.lib.rptgpu_render_batch_reduce(self.handle, C.byref(cam), C.byref(params), int(root),
+                                                   out.ctypes.data_as(C.POINTER(C.c_float)))
+        _abi.check(code, self.handle)
+        return out
+
     def closest_hit(self, origins, dirs, precision=_abi.RPT_PRECISION_F64_STRICT):
         o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)

@@ -504,6 +504,30 @@ def test_flat_scenes_exact_ties_and_coplanar_surfaces(oracle):
     g.close()
 
 
+def test_library_collective_single_rank_communicator(built):
+    """rptgpu_comm_* / rptgpu_render_batch_reduce: a real RCCL communicator of one rank (all this box has) —
+    the reduce runs through ncclReduce on the library's stream and the frame equals render_batch rounded to f32.
+    Without a communicator the same call is a plain render + D2H."""
+    scene, cam, p, g = built("cornell")
+    ref = g.render_batch(cam, p).astype(np.float32).ravel()
+    plain = g.render_batch_reduce(cam, p, root=0)
+    assert (plain == ref).all()
+    g2 = GpuScene(scene, 0)
+    g2.comm_init(0, 1, GpuScene.comm_unique_id())
+    with pytest.raises(rpt_amd.RptGpuError):
+        g2.comm_init(0, 1, GpuScene.comm_unique_id())  # one communicator per handle
+    a = g2.render_batch_reduce(cam, p, root=0)
+    # the partition fields of the caller are overridden by (rank, world)
+    pp = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, tile=(4, 4), part=(1, 3))
+    b = g2.render_batch_reduce(cam, pp, root=0)
+    assert (a == ref).all() and (b == ref).all()
+    with pytest.raises(rpt_amd.RptGpuError):
+        g2.render_batch_reduce(cam, p, root=1)
+    g2.comm_destroy()
+    assert (g2.render_batch_reduce(cam, p, root=0) == ref).all()
+    g2.close()
+
+
 def test_scene_destroy_releases_device_memory():
     # every device allocation behind a handle (scene, workspace, per-sample radiance buffer, sort buffers) is
     # returned by rptgpu_scene_destroy: create / render / destroy in a loop keeps free HBM where it was
