@@ -13,7 +13,10 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <future>
 #include <map>
+#include <thread>
+#include <cstdlib>
 
 namespace rpthost {
 
@@ -47,13 +50,13 @@ struct Builder {
 
   // cell = the node's box as the reference derives it while traversing: the root bounds cut by the
   // ancestors' split planes (BoundingBox::split, kdtree.rs:71-86)
-  void construct(uint32_t id, std::vector<uint32_t>& idx, uint32_t depth, Box cell) {
-    out.max_depth = std::max(out.max_depth, depth);
+  // the decision of construct (kdtree.rs:235-319) for the primitives `idx`: leaf, or (axis, value) and the two
+  // index lists (straddlers in both, kdtree.rs:270-281)
+  void decide(const std::vector<uint32_t>& idx, bool& leaf, int& split_dir, double& value, std::vector<uint32_t>& left,
+              std::vector<uint32_t>& right) {
     size_t n = idx.size();
-    if (n < 16) { // kdtree.rs:236-238
-      make_leaf(id, idx);
-      return;
-    }
+    leaf = true;
+    if (n < 16) return; // kdtree.rs:236-238
     xs.clear(); ys.clear(); zs.clear();
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i : idx) {
@@ -69,19 +72,16 @@ struct Builder {
     double m[3] = {median_of(xs), median_of(ys), median_of(zs)}; // kdtree.rs:252-255
     size_t s[3];
     for (int dim = 0; dim < 3; dim++) { // partition_score kdtree.rs:257-268
-      size_t left = 0, right = 0;
+      size_t l = 0, r = 0;
       for (uint32_t i : idx) {
-        if (boxes[i].lo[dim] <= m[dim]) left++;
-        if (boxes[i].hi[dim] >= m[dim]) right++;
+        if (boxes[i].lo[dim] <= m[dim]) l++;
+        if (boxes[i].hi[dim] >= m[dim]) r++;
       }
-      s[dim] = std::max(left, right);
+      s[dim] = std::max(l, r);
     }
     size_t threshold = (size_t)((double)n * SCORE_THRESHOLD); // kdtree.rs:286
-    if (std::min(std::min(s[0], s[1]), s[2]) >= threshold) {
-      make_leaf(id, idx);
-      return;
-    }
-    int split_dir = -1; // kdtree.rs:291-319
+    if (std::min(std::min(s[0], s[1]), s[2]) >= threshold) return;
+    split_dir = -1; // kdtree.rs:291-319
     double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     if (ex > ey && ex > ez) {
       if (s[0] < threshold) split_dir = 0;
@@ -95,37 +95,118 @@ struct Builder {
       else if (s[1] < s[2]) split_dir = 1;
       else split_dir = 2;
     }
-    std::vector<uint32_t> left, right; // partition kdtree.rs:270-281 (straddlers go to both)
-    for (uint32_t i : idx) {
-      if (boxes[i].lo[split_dir] <= m[split_dir]) left.push_back(i);
-      if (boxes[i].hi[split_dir] >= m[split_dir]) right.push_back(i);
+    value = m[split_dir];
+    left.clear(); right.clear();
+    for (uint32_t i : idx) { // partition kdtree.rs:270-281 (straddlers go to both)
+      if (boxes[i].lo[split_dir] <= value) left.push_back(i);
+      if (boxes[i].hi[split_dir] >= value) right.push_back(i);
+    }
+    leaf = false;
+  }
+
+  // cell = the node's box as the reference derives it while traversing: the root bounds cut by the
+  // ancestors' split planes (BoundingBox::split, kdtree.rs:71-86)
+  void construct(uint32_t id, std::vector<uint32_t>& idx, uint32_t depth, Box cell) {
+    out.max_depth = std::max(out.max_depth, depth);
+    bool leaf;
+    int split_dir = -1;
+    double value = 0.0;
+    std::vector<uint32_t> left, right;
+    decide(idx, leaf, split_dir, value, left, right);
+    if (leaf) {
+      make_leaf(id, idx);
+      return;
     }
     std::vector<uint32_t>().swap(idx); // release before recursing
     uint32_t l = (uint32_t)out.nodes.size();
     out.nodes.push_back({});
     out.nodes.push_back({});
-    out.nodes[id].split = m[split_dir];
+    out.nodes[id].split = value;
     out.nodes[id].a = l;
     out.nodes[id].ib = (uint32_t)split_dir;
     // the median of the primitives' box edges can fall outside the cell (straddlers reach beyond
     // it); the device's compact traversal assumes it does not and is disabled for such trees
-    if (!(m[split_dir] >= cell.lo[split_dir] && m[split_dir] <= cell.hi[split_dir])) out.regular = false;
+    if (!(value >= cell.lo[split_dir] && value <= cell.hi[split_dir])) out.regular = false;
     Box cl = cell, cr = cell;
-    cl.hi[split_dir] = m[split_dir];
-    cr.lo[split_dir] = m[split_dir];
+    cl.hi[split_dir] = value;
+    cr.lo[split_dir] = value;
     construct(l, left, depth + 1, cl);
     construct(l + 1, right, depth + 1, cr);
   }
 };
 
+// ---- parallel construction -----------------------------------------------------------------------------------
+// construct() numbers nodes in the order a sequential depth-first build creates them: a node's two children are
+// allocated as a pair when the node is split, then the whole left subtree, then the whole right subtree; leaf
+// entries are appended to refs[] in the same order.  So a subtree built on its own (root = local node 0) can be
+// spliced in afterwards by shifting indices: the numbering — hence the tree the device traverses and every
+// fixture — is identical whatever the number of threads.  Subtrees above PAR_MIN_PRIMS primitives in the first
+// PAR_MAX_DEPTH levels fork their left child onto another thread (std::async); everything below runs the
+// sequential builder.  (The reference builds sequentially with three full sorts per node, kdtree.rs:252-255.)
+constexpr size_t PAR_MIN_PRIMS = 8192;
+constexpr uint32_t PAR_MAX_DEPTH = 5;
+
+void splice(KdBuild& dst, uint32_t dst_root, const KdBuild& sub) {
+  // sub's node 0 becomes dst.nodes[dst_root]; sub's nodes 1.. are appended; child and ref indices shift
+  const uint32_t node_shift = (uint32_t)dst.nodes.size() - 1u, ref_shift = (uint32_t)dst.refs.size();
+  auto fix = [&](rptdev::KdNode n) {
+    if ((n.ib & 3u) == 3u) n.a += ref_shift;
+    else n.a += node_shift;
+    return n;
+  };
+  dst.nodes[dst_root] = fix(sub.nodes[0]);
+  for (size_t i = 1; i < sub.nodes.size(); i++) dst.nodes.push_back(fix(sub.nodes[i]));
+  dst.refs.insert(dst.refs.end(), sub.refs.begin(), sub.refs.end());
+  dst.max_depth = std::max(dst.max_depth, sub.max_depth);
+  dst.regular = dst.regular && sub.regular;
+}
+
+void build_subtree(const std::vector<Box>& boxes, std::vector<uint32_t>& idx, uint32_t depth, Box cell, KdBuild& out, int threads);
+
+// one split at the top of a large subtree, children built concurrently, then spliced in sequential order
+void build_forked(const std::vector<Box>& boxes, std::vector<uint32_t>& idx, uint32_t depth, Box cell, KdBuild& out, int threads) {
+  // the split decision is the sequential builder's own (Builder::decide)
+  struct { std::vector<uint32_t> left, right; int dir = -1; double value = 0.0; bool leaf = false; } pb;
+  {
+    KdBuild scratch;
+    Builder probe{boxes, scratch, {}, {}, {}};
+    probe.decide(idx, pb.leaf, pb.dir, pb.value, pb.left, pb.right);
+  }
+  out.nodes.clear(); out.refs.clear(); out.max_depth = depth; out.regular = true;
+  out.nodes.push_back({});
+  if (pb.leaf) {
+    out.nodes[0].split = 0.0; out.nodes[0].a = 0; out.nodes[0].ib = 3u | ((uint32_t)idx.size() << 2);
+    out.refs = idx;
+    return;
+  }
+  std::vector<uint32_t>().swap(idx);
+  out.nodes.push_back({}); out.nodes.push_back({});
+  out.nodes[0].split = pb.value; out.nodes[0].a = 1; out.nodes[0].ib = (uint32_t)pb.dir;
+  if (!(pb.value >= cell.lo[pb.dir] && pb.value <= cell.hi[pb.dir])) out.regular = false;
+  Box cl = cell, cr = cell;
+  cl.hi[pb.dir] = pb.value; cr.lo[pb.dir] = pb.value;
+  KdBuild lb, rb;
+  auto fut = std::async(std::launch::async, [&] { build_subtree(boxes, pb.left, depth + 1, cl, lb, threads / 2); });
+  build_subtree(boxes, pb.right, depth + 1, cr, rb, threads - threads / 2);
+  fut.get();
+  splice(out, 1, lb);
+  splice(out, 2, rb);
+}
+
+void build_subtree(const std::vector<Box>& boxes, std::vector<uint32_t>& idx, uint32_t depth, Box cell, KdBuild& out, int threads) {
+  if (threads > 1 && idx.size() >= PAR_MIN_PRIMS && depth < PAR_MAX_DEPTH) {
+    build_forked(boxes, idx, depth, cell, out, threads);
+    return;
+  }
+  out.nodes.clear(); out.refs.clear(); out.max_depth = 0; out.regular = true;
+  out.nodes.push_back({});
+  Builder b{boxes, out, {}, {}, {}};
+  b.construct(0, idx, depth, cell);
+}
+
 } // namespace
 
-void kd_build(const std::vector<Box>& boxes, KdBuild& out) {
-  out.nodes.clear();
-  out.refs.clear();
-  out.max_depth = 0;
-  out.regular = true;
-  out.nodes.push_back({});
+void kd_build(const std::vector<Box>& boxes, KdBuild& out, int threads) {
   std::vector<uint32_t> idx(boxes.size());
   Box root;
   for (int k = 0; k < 3; k++) { root.lo[k] = INFINITY; root.hi[k] = -INFINITY; }
@@ -136,8 +217,12 @@ void kd_build(const std::vector<Box>& boxes, KdBuild& out) {
       root.hi[k] = std::fmax(root.hi[k], boxes[i].hi[k]);
     }
   }
-  Builder b{boxes, out, {}, {}, {}};
-  b.construct(0, idx, 0, root);
+  if (threads <= 0) {
+    threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (const char* e = std::getenv("RPTGPU_BUILD_THREADS")) threads = std::max(1, std::atoi(e));
+    threads = std::min(threads, 32);
+  }
+  build_subtree(boxes, idx, 0, root, out, threads);
 }
 
 // ------------------------------------------------------------------------- flattening

@@ -21,7 +21,9 @@ struct KdBuild {
 };
 
 // KdTree::new (kdtree.rs:108-119) -> construct (kdtree.rs:235-345), flattened.
-void kd_build(const std::vector<Box>& boxes, KdBuild& out);
+// threads <= 0: std::thread::hardware_concurrency() (RPTGPU_BUILD_THREADS overrides), at most 32; the tree is the same
+// for any thread count (host_scene.cpp, splice)
+void kd_build(const std::vector<Box>& boxes, KdBuild& out, int threads = 0);
 
 struct FlatScene {
   std::vector<rptdev::Inst> insts;

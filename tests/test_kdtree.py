@@ -143,3 +143,18 @@ def test_full_size_mesh_tree_is_the_reference_rule_tree(oracle):
         assert (a[k] == b[k]).all(), k
     assert a["max_depth"] == b["max_depth"] >= 15
     assert len(a["refs"]) > 4 * len(tris)  # straddlers go to both sides (kdtree.rs:270-281): ~5x duplication
+
+
+def test_parallel_build_gives_the_same_tree_for_any_thread_count(monkeypatch):
+    """subtrees above 8192 primitives are built on other threads and spliced in the order the
+    sequential depth-first build numbers nodes (host_scene.cpp, splice) — node for node the same tree."""
+    tris = scenes.knot_mesh(nu=784, nv=64)
+    boxes = np.ascontiguousarray(tri_boxes(tris))
+    trees = {}
+    for th in (1, 2, 5, 32):
+        monkeypatch.setenv("RPTGPU_BUILD_THREADS", str(th))
+        trees[th] = kdtree_build(boxes, _abi.load_library(), "rptgpu")
+    for th in (2, 5, 32):
+        for k in ("split", "info", "a", "b", "refs"):
+            assert (trees[1][k] == trees[th][k]).all(), (th, k)
+        assert trees[1]["max_depth"] == trees[th]["max_depth"] and trees[1]["regular"] == trees[th]["regular"]
