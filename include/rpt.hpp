@@ -16,6 +16,7 @@
 #include <fstream>
 #include <functional>
 #include <istream>
+#include <map>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -419,6 +420,83 @@ struct Object {
   explicit Object(Shape s) : shape(std::move(s)) {}
   Object material(const Material& m) const { Object o = *this; o.material_ = m; return o; }
 };
+
+// ---- io.rs:202-254 load_mtl, io.rs:83-148 load_obj_with_mtl ----
+inline std::map<std::string, Material> load_mtl(std::istream& in) {
+  std::map<std::string, Material> materials;
+  std::string current, line;
+  bool have = false;
+  while (std::getline(in, line)) {
+    std::vector<std::string> t = io_detail::tokens(line);
+    if (t.empty() || t[0][0] == '#') continue;
+    if (t[0] == "newmtl") {
+      if (t.size() < 2) throw std::runtime_error("newmtl without a name");
+      current = t[1];
+      have = true;
+      materials.emplace(current, Material()); // entry().or_default()
+    } else {
+      if (!have) throw std::runtime_error("Material was not specified with `newmtl` before properties were added");
+      Material& mat = materials[current];
+      // best-effort conversion from Ka/Kd/Ks to the physically-based material (io.rs:226-251)
+      if (t[0] == "Kd") {
+        mat.color = io_detail::point(t);
+      } else if (t[0] == "Ns") {
+        if (t.size() < 2) throw std::runtime_error("Could not parse Ks value");
+        mat.roughness = std::sqrt(std::sqrt(2.0 / (io_detail::number(t[1]) + 2.0)));
+      } else if (t[0] == "Ni") {
+        if (t.size() < 2) throw std::runtime_error("Could not parse Ns value");
+        mat.index = std::fmax(io_detail::number(t[1]), 1.0 + 1e-4); // an IOR of exactly 1.0 cannot be handled
+      } else if (t[0] == "d") {
+        if (t.size() < 2) throw std::runtime_error("Could not parse d value");
+        if (io_detail::number(t[1]) < 0.8) mat.transparent_ = true;
+      }
+    }
+  }
+  return materials;
+}
+
+// one Object per run of faces under one `usemtl` (a mesh with several materials is several objects, io.rs:122-147)
+inline std::vector<Object> load_obj_with_mtl(std::istream& obj, std::istream& mtl) {
+  std::map<std::string, Material> materials = load_mtl(mtl);
+  std::vector<Vec3> vertices, normals;
+  std::vector<Object> objects;
+  std::vector<Triangle> current_triangles;
+  Material current_material;
+  std::string last_usemtl, line;
+  bool have_last = false;
+  auto flush = [&]() {
+    if (!current_triangles.empty()) {
+      objects.push_back(Object(Mesh(current_triangles)).material(current_material));
+      current_triangles.clear();
+    }
+  };
+  while (std::getline(obj, line)) {
+    std::vector<std::string> t = io_detail::tokens(line);
+    if (t.empty() || t[0][0] == '#') continue;
+    if (t[0] == "v") vertices.push_back(io_detail::point(t));
+    else if (t[0] == "vn") normals.push_back(io_detail::point(t));
+    else if (t[0] == "f") io_detail::face(t, vertices, normals, current_triangles);
+    else if (t[0] == "usemtl") {
+      if (t.size() < 2) throw std::runtime_error("usemtl without a name");
+      if (!have_last || last_usemtl != t[1]) {
+        flush();
+        auto it = materials.find(t[1]);
+        if (it == materials.end()) throw std::runtime_error("Could not found `usemtl " + t[1] + "` in library");
+        current_material = it->second;
+        last_usemtl = t[1];
+        have_last = true;
+      }
+    }
+  }
+  flush();
+  return objects;
+}
+inline std::vector<Object> load_obj_with_mtl(const std::string& obj_path, const std::string& mtl_path) {
+  std::ifstream o(obj_path), m(mtl_path);
+  if (!o) throw std::runtime_error("cannot open " + obj_path);
+  if (!m) throw std::runtime_error("cannot open " + mtl_path);
+  return load_obj_with_mtl(o, m);
+}
 
 // ---- light.rs:7-19 ----
 struct Light {
