@@ -389,7 +389,7 @@ struct Flattener {
         is_bounded = false;
         break;
       case RPT_SHAPE_MONOMIAL:
-        if (nesting > 0) { err = "MonomialSurface inside KdTree<Box<dyn Bounded>> is not supported"; return RPTGPU_E_UNSUPPORTED_SHAPE; }
+        if (nesting > 0) fs.nested_mesh = true; // a tree child of the extended set: the *_ext kernel builds
         if (s.monomial_exp != 4.0) {
           err = "MonomialSurface: intersection and normals are only defined for exp = 4 (monomial_surface.rs:10)";
           return RPTGPU_E_UNSUPPORTED_SHAPE;
@@ -441,14 +441,19 @@ struct Flattener {
         break;
       }
       case RPT_SHAPE_GROUP: {
-        if (nesting > 0) { err = "nested KdTree<Box<dyn Bounded>>"; return RPTGPU_E_UNSUPPORTED_SHAPE; }
+        // KdTree<Box<dyn Bounded>> forwards Bounded through Box (kdtree.rs:14-24), so a group can sit in a group;
+        // the device walks ONE inner level with its own stack (kernels/traversal.inc), deeper nesting is refused
+        if (nesting > 1) { err = "KdTree<Box<dyn Bounded>> nested more than two levels deep"; return RPTGPU_E_UNSUPPORTED_SHAPE; }
+        if (nesting > 0) fs.nested_mesh = true;
         if (!s.children && s.num_children) { err = "null children"; return RPTGPU_E_INVALID_ARGUMENT; }
         std::vector<rptdev::Inst> kids(s.num_children);
         std::vector<Box> boxes(s.num_children);
         for (uint64_t i = 0; i < s.num_children; i++) {
           const RptShape& c = s.children[i];
-          if (c.kind != RPT_SHAPE_SPHERE && c.kind != RPT_SHAPE_CUBE && c.kind != RPT_SHAPE_MESH) {
-            err = "KdTree<Box<dyn Bounded>> children must be spheres, cubes or meshes (optionally Transformed)";
+          if (c.kind != RPT_SHAPE_SPHERE && c.kind != RPT_SHAPE_CUBE && c.kind != RPT_SHAPE_MESH &&
+              c.kind != RPT_SHAPE_MONOMIAL && c.kind != RPT_SHAPE_GROUP) {
+            err = "KdTree<Box<dyn Bounded>> children must be Bounded: spheres, cubes, meshes, monomial surfaces or groups "
+                  "(optionally Transformed); a Plane is not (kdtree.rs:9-12)";
             return RPTGPU_E_UNSUPPORTED_SHAPE;
           }
           bool b = true;

@@ -44,7 +44,8 @@ struct FlatScene {
   int32_t num_objects = 0;
   int32_t num_shadow_lights = 0;
   uint32_t max_tree_depth = 0;
-  bool nested_mesh = false; // some KdTree<Box<dyn Bounded>> child is a Mesh (kd-tree of kd-trees)
+  bool nested_mesh = false; // some KdTree<Box<dyn Bounded>> child is a Mesh, a MonomialSurface or another group:
+                            // the scene needs the extended kernel builds
 };
 
 // returns RPTGPU_OK or an error code; `err` explains

@@ -18,8 +18,8 @@ from oracle import oracle_ffi as O  # noqa: E402
 import small_scenes  # noqa: E402
 
 
-def main(only_hi=False):
-    for name in ([] if only_hi else small_scenes.NAMES):
+def main(only_hi=False, only=None):
+    for name in ([] if only_hi else (only or small_scenes.NAMES)):
         scene, cam, p = small_scenes.small(name)
         osc = O.OracleScene(scene)
         img, cnt = osc.render(cam, p, threads=0, counters=True)
@@ -32,7 +32,7 @@ def main(only_hi=False):
                             hit_obj=obj, counters=np.array([cnt[k] for k in sorted(cnt)], dtype=np.int64),
                             counter_names=np.array(sorted(cnt)))
         print(name, img.shape, "mean", img.mean(axis=0), "hits", int((obj >= 0).sum()), "/", len(obj))
-    for name in small_scenes.HI_NAMES:  # image only (~10^6 samples each)
+    for name in ([] if only else small_scenes.HI_NAMES):  # image only (~10^6 samples each)
         scene, cam, p = small_scenes.small(name)
         img = O.OracleScene(scene).render(cam, p, threads=0)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img)
@@ -40,4 +40,4 @@ def main(only_hi=False):
 
 
 if __name__ == "__main__":
-    main(only_hi="--hi" in sys.argv)
+    main(only_hi="--hi" in sys.argv, only=[a for a in sys.argv[1:] if not a.startswith("--")] or None)

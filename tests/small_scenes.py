@@ -64,6 +64,33 @@ def monomial():
     return scene, camera
 
 
+def nested_groups():
+    """KdTree<Box<dyn Bounded>> inside KdTree<Box<dyn Bounded>> (Bounded is forwarded through Box, kdtree.rs:14-24) with
+    every Bounded shape as a tree child: spheres, cubes, a mesh, monomial surfaces (monomial_surface.rs:183-190) —
+    transformed and not — plus a lamp that is itself a group of groups (KdTree::sample through two levels)."""
+    scene = Scene()
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0x999999))))
+    mesh = Mesh(scenes.knot_mesh(24, 6))
+    ring = [sphere().scale((0.18, 0.18, 0.18)).translate((math.cos(a) * 0.9, 0.0, math.sin(a) * 0.9))
+            for a in np.linspace(0, 2 * math.pi, 18, endpoint=False)]
+    inner = KdTree(ring + [cube().scale((0.4, 0.4, 0.4)).rotate_y(0.5), monomial_surface(0.6, 4.0).scale((0.5, 0.5, 0.5)).translate((0.0, 0.3, 0.0))])
+    kids = [inner.translate((-1.6, -0.2, 0.0)), inner.scale((0.7, 1.3, 0.7)).rotate_z(0.4).translate((1.7, 0.3, -0.5)),
+            mesh.scale((1.2, 1.2, 1.2)).translate((0.0, 0.9, -1.2)), monomial_surface(1.5, 4.0).translate((0.0, -1.0, 1.2)),
+            monomial_surface(0.8, 4.0).rotate_x(math.pi).scale((0.6, 0.6, 0.6)).translate((0.2, 2.4, 0.4)), sphere(), cube().translate((0.0, 0.0, -3.0))]
+    kids += [sphere().scale((0.12, 0.12, 0.12)).translate((-2.5 + 0.3 * i, -0.85, 2.0)) for i in range(16)]
+    scene.add(Object(KdTree(kids)).material(Material.specular(hex_color(0x6688CC), 0.3)))
+    scene.add(Object(KdTree([inner.translate((0.0, 1.6, 1.5)), cube().scale((0.3, 0.3, 0.3)).translate((0.9, 1.6, 1.5))]).rotate_y(0.3))
+              .material(Material.clear(1.5, 0.05)))
+    scene.add(Light.Ambient((0.02, 0.02, 0.03)))
+    scene.add(Light.Point((25.0, 25.0, 22.0), (2.0, 4.0, 4.0)))
+    lamp = KdTree([KdTree([sphere().scale((0.15, 0.15, 0.15)).translate((0.3 * i, 3.2, 0.0)) for i in range(3)]).translate((-0.5, 0.0, 1.0)),
+                   cube().scale((0.3, 0.05, 0.3)).translate((1.5, 3.0, 1.0)),
+                   monomial_surface(0.3, 4.0).rotate_x(math.pi).scale((0.4, 0.4, 0.4)).translate((-1.5, 3.4, 0.5))])
+    scene.add(Light.Object(Object(lamp).material(Material.light((1.0, 0.95, 0.85), 45.0))))
+    camera = Camera.look_at((0.4, 2.4, 6.5), (0.0, 0.4, 0.0), (0.0, 1.0, 0.0), 0.75)
+    return scene, camera
+
+
 def small(name):
     """-> (scene, camera, params) for the named small config."""
     if name == "sphere":
@@ -112,6 +139,9 @@ def small(name):
                                           sphere().scale((0.2, 0.2, 0.2)).translate((2.2, 2.5, 3.0))]))
                            .material(Material.light((1.0, 0.9, 0.8), 25.0))))
         return s, c, make_params(64, 48, 3, 4, seed=113)
+    if name == "nested_groups":
+        s, c = nested_groups()
+        return s, c, make_params(64, 40, 4, 4, seed=114)
     # the same scenes at 256x144 with 32 spp: ~10^6 samples each, so that draw sequences a 64x36 frame at 4 spp
     # hardly ever produces (long rejection loops, TIR, gen_range redraws, deep clamp chains) do occur
     if name == "cornell_hi":
@@ -125,4 +155,4 @@ def small(name):
 
 HI_NAMES = ["cornell_hi", "coverage_hi"]
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
-         "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots"]
+         "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots", "nested_groups"]

@@ -97,3 +97,32 @@ def test_scene_generators_are_deterministic():
     assert 12000 < len(g) < 20000 and np.isfinite(g).all()
     h1, h2 = rpt_amd.scenes.synthetic_hdri(64, 32), rpt_amd.scenes.synthetic_hdri(64, 32)
     assert (h1.buf == h2.buf).all() and h1.buf.max() <= 60.0 and h1.buf.min() >= 0.0
+
+
+def test_shape_nesting_limits_are_reported_at_scene_create():
+    """KdTree<Box<dyn Bounded>> children: every Bounded shape incl. another group (one level) is accepted by the
+    flattener — which runs before the device is touched, so without a GPU the error is NO_DEVICE, not UNSUPPORTED;
+    a third level, or a Plane (not Bounded, kdtree.rs:9-12) as a child, is UNSUPPORTED_SHAPE."""
+    import rpt_amd
+    from rpt_amd import GpuScene, KdTree, Object, Scene, _abi, cube, monomial_surface, plane, sphere
+
+    def code_of(shape):
+        s = Scene()
+        s.add(Object(shape))
+        try:
+            GpuScene(s, 0).close()
+            return 0
+        except rpt_amd.RptGpuError as e:
+            return e.code
+
+    ok = (0, _abi.RPTGPU_E_NO_DEVICE)
+    two = KdTree([KdTree([sphere(), cube().translate((2.0, 0.0, 0.0))]).translate((0.0, 1.0, 0.0)), monomial_surface(1.0, 4.0), sphere()])
+    assert code_of(two) in ok
+    three = KdTree([KdTree([KdTree([sphere()]), cube()]), sphere()])
+    assert code_of(three) == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
+    with __import__("pytest").raises(rpt_amd.RptGpuError) as e:
+        KdTree([sphere(), plane((0.0, 1.0, 0.0), 0.0)]).lower
+        s = Scene()
+        s.add(Object(KdTree([sphere(), plane((0.0, 1.0, 0.0), 0.0)])))
+        GpuScene(s, 0)
+    assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
