@@ -156,7 +156,9 @@ struct rptgpu_scene {
   struct Pending { int kind; int e0, e1; };
   std::vector<Pending> pending;
   int ev_used = 0;
-  uint64_t target_paths = 4u << 20; // paths in flight per pass
+  uint64_t target_paths = 0;       // RPTGPU_TARGET_PATHS: paths in flight per pass of the wavefront pipeline; 0 = as many as
+                                   // the workspace budget holds (ws_budget_bytes and half of the free HBM), at most 128 Mi
+  uint64_t ws_budget_bytes = 96ull << 30; // RPTGPU_WS_BYTES
   // multi-GPU: the communicator of this handle (rptgpu_comm_init) and its frame buffers
   RcclComm comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -427,7 +429,24 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       h->stats.extend_rays += rc[0];
       h->stats.shadow_rays += rc[1];
     } else if (npix) {
-      uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, h->target_paths / npix));
+      // Paths in flight per pass.  Late bounces keep few paths alive, and a depth's kernels need ~10^5 rays to fill
+      // 256 CUs, so the more paths start together the better the deep bounces run (C3 stand-in: 4 Mi -> 71, 16 Mi ->
+      // 106, 128 Mi -> 128 Msamples/s; 16k-triangle glass 179 -> 324).  288 GB of HBM is what makes that affordable:
+      // a path slot is ~0.8 KB at 8 bounces, so 128 Mi paths are ~100 GB of workspace.
+      uint64_t target = h->target_paths;
+      if (!target) {
+        const uint64_t nl = (uint64_t)std::max(1, h->dscene.num_lights);
+        uint64_t per_path = 6 * 8 + 4 * 8 + 4 + 4 + 1 + (uint64_t)(p->max_bounces + 1) * rptdev::REC_FIELDS * 8 +
+                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + (h->has_deep ? 4 + nl * 8 + (h->sort_rays ? 12 + 16 : 0) : 0);
+        uint64_t budget = h->ws_budget_bytes;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+          uint64_t have = h->ws_cap * per_path; // what this handle already holds counts as available
+          budget = std::min<uint64_t>(budget, (free_b + have) / 2);
+        }
+        target = std::min<uint64_t>(128ull << 20, std::max<uint64_t>(4ull << 20, budget / per_path));
+      }
+      uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, target / npix));
       ensure_workspace(h, (uint64_t)npix * s_chunk, p->max_bounces);
       h->accum.alloc((uint64_t)npix * 3);
       HIP_TRY(hipMemsetAsync(h->accum.p, 0, (uint64_t)npix * 3 * sizeof(double), st));
@@ -697,6 +716,10 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) {
       uint64_t v = std::strtoull(e, nullptr, 10);
       if (v >= 1024) h->target_paths = v;
+    }
+    if (const char* e = std::getenv("RPTGPU_WS_BYTES")) {
+      uint64_t v = std::strtoull(e, nullptr, 10);
+      if (v >= (1ull << 20)) h->ws_budget_bytes = v;
     }
   } catch (const HipError& e) {
     int code = hip_fail(nullptr, e);
