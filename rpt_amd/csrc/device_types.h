@@ -1,5 +1,5 @@
 // device_types.h — the flattened, device-resident scene and the wavefront path state.
-// Shared by the host flattener/API (flatten.cpp, api.cpp) and the gfx950 kernels.
+// Shared by the host flattener / API (host_scene.cpp, api.cpp) and the gfx950 kernels.
 //
 // Layout rules (MI355X): everything a lane gathers on its own (kd nodes, triangles, group
 // children) is a 16-byte-aligned record so one `global_load_dwordx4` (or a run of them) fetches

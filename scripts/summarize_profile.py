@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 scene = sys.argv[2] if len(sys.argv) > 2 else "cornell"
 src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, scene))
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("RPT_PROFILE_DST") or os.path.join(ROOT, "profiles")  # on the GPU box: a directory under gpurun_out/
 os.makedirs(dst, exist_ok=True)
 pre = os.path.join(dst, "%s_%s" % (tag, scene))
 NUM_SIMD, NUM_SE = 1024, 32  # MI355X: 256 CUs x 4 SIMDs; 8 XCDs x 4 shader engines
