@@ -279,9 +279,10 @@ void fill_trix(const RptTriangle& t, rptdev::TriX& x) {
   x.denom = x.d00 * x.d11 - x.d01 * x.d01;
 }
 
-// Conservative 16-bit boxes of a mesh's leaf entries (device_types.h LeafBox).  Grid: 65533 steps across the
-// tree's bounds per axis; a minimum is rounded down and a maximum up, then both move one more step outwards, so
-// the decoded box contains the triangle's true box with a margin of at least (1 - 1e-12) steps on every side —
+// Conservative 16-bit boxes of a mesh's leaf entries (device_types.h LeafBox).  Grid: 65529 steps across the
+// tree's bounds per axis plus two steps of padding on either side; a minimum is rounded down and a maximum up, then
+// both move one more step outwards, so the decoded box contains the triangle's true box with a margin of at least
+// (1 - 1e-12) steps on every side —
 // orders of magnitude more than the rounding of the decode and of the slab arithmetic on the device.  A triangle
 // whose barycentric system is ill-conditioned (sliver: rounding in mesh.rs:64-73 could accept a point that is not
 // near the triangle) or that has a non-finite vertex gets the whole grid, i.e. it is never filtered.  GROUP trees get
@@ -289,10 +290,13 @@ void fill_trix(const RptTriangle& t, rptdev::TriX& x) {
 void fill_leaf_boxes(FlatScene& fs, int tree, int64_t tri_base /* < 0: a GROUP tree, entries are placed shapes */,
                      const std::vector<Box>& boxes) {
   rptdev::Tree& t = fs.trees[tree];
+  // the grid is two steps larger than the bounds on every side: a coordinate of a primitive maps to [2, 65531], so the
+  // outward rounding below (floor - 1, ceil + 1) never reaches the clamp, i.e. a box on a face of the tree's bounds
+  // keeps its margin too (tests/test_leaf_boxes.py found the case: a vertex on the bounds, a hit exactly there)
   for (int k = 0; k < 3; k++) {
     double ext = t.bounds[3 + k] - t.bounds[k];
-    t.qlo[k] = t.bounds[k];
-    t.qscale[k] = (ext > 0.0 && std::isfinite(ext)) ? ext / 65533.0 : 1.0;
+    t.qscale[k] = (ext > 0.0 && std::isfinite(ext)) ? ext / 65529.0 : 1.0;
+    t.qlo[k] = t.bounds[k] - 2.0 * t.qscale[k];
   }
   size_t nrefs = fs.refs.size() - t.ref_base;
   fs.lbox.resize(fs.refs.size());

@@ -1,0 +1,147 @@
+"""The conservative leaf boxes in front of Triangle::intersect (rpt_amd/csrc/host_scene.cpp fill_leaf_boxes,
+kernels/shapes.inc leaf_box_pass / boxray_make) restated in numpy, and their one obligation checked on millions of
+(ray, triangle) pairs: **whenever the exact test of mesh.rs:49-82 accepts, the filter passes** — for the widest window
+and for windows that barely contain the hit — including rays that graze edges and vertices, rays almost parallel to
+an axis, triangles at the corners of the grid, slivers, and origins far from the mesh.  (That the DEVICE code is this
+filter is what the bit-exact GPU parity tests show: a filter that dropped an accepted hit would change an image.)"""
+import numpy as np
+
+from rpt_amd import scenes
+
+GRID = 65529.0   # plus two steps of padding on either side of the bounds
+
+
+def quantise(tris, lo, hi):
+    """fill_leaf_boxes: (n, 6) uint grid boxes of (n, 9) triangles in the tree bounds [lo, hi]"""
+    ext = hi - lo
+    scale = np.where((ext > 0) & np.isfinite(ext), ext / GRID, 1.0)
+    lo = lo - 2.0 * scale
+    v = tris.reshape(-1, 3, 3)
+    bmin, bmax = v.min(axis=1), v.max(axis=1)
+    a = np.clip(np.floor((bmin - lo) / scale) - 1.0, 0.0, 65535.0)
+    c = np.clip(np.ceil((bmax - lo) / scale) + 1.0, 0.0, 65535.0)
+    d0, d1 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    d00, d01, d11 = (d0 * d0).sum(1), (d0 * d1).sum(1), (d1 * d1).sum(1)
+    denom = d00 * d11 - d01 * d01
+    full = ~(denom > 1e-10 * (d00 * d11)) | ~np.isfinite(denom)
+    a[full], c[full] = 0.0, 65535.0
+    # the decoded box contains the true box with a margin of (almost) one step on every side — also on the bounds' faces
+    nf = ~full
+    assert (lo + a[nf] * scale <= bmin[nf] - 0.999 * scale).all() and (lo + c[nf] * scale >= bmax[nf] + 0.999 * scale).all()
+    return np.concatenate([a, c], axis=1), scale, lo, full
+
+
+def box_pass(q, scale, lo, o, d, t_lo, t_hi):
+    """boxray_make + leaf_box_pass for pairs (q[i], ray i); returns (pass, filter_on)"""
+    with np.errstate(all="ignore"):
+        r = 1.0 / d
+        a = scale * r
+        b = (lo - o) * r
+        aa, am, bm = np.abs(a).min(axis=1), np.abs(a).max(axis=1), np.abs(b).max(axis=1)
+        on = (d != 0).all(axis=1) & (aa > 0) & (am < 1e150) & (bm < 1e150) & (bm < 1e10 * aa)
+        t0 = q[:, 0:3] * a + b   # the device uses fma: one rounding less
+        t1 = q[:, 3:6] * a + b
+        near, far = np.fmin(t0, t1), np.fmax(t0, t1)
+        tl = np.fmax(np.fmax(near[:, 0], near[:, 1]), near[:, 2])
+        th = np.fmin(np.fmin(far[:, 0], far[:, 1]), far[:, 2])
+        ok = (tl <= th) & (th >= t_lo) & (tl <= t_hi)
+    return ok | ~on, on
+
+
+def exact_hit(tris, o, d):
+    """Triangle::intersect (mesh.rs:49-82) with t_min = 1e-12 and record.time = +inf: (accepted, time)"""
+    with np.errstate(all="ignore"):
+        v1, v2, v3 = tris[:, 0:3], tris[:, 3:6], tris[:, 6:9]
+        d0, d1 = v2 - v1, v3 - v1
+        n = np.cross(d0, d1)
+        n = n / np.sqrt((n * n).sum(1, keepdims=True))
+        cosine = (n * d).sum(1)
+        time = (n * (v1 - o)).sum(1) / cosine
+        d2 = (o + time[:, None] * d) - v1
+        d00, d01, d11 = (d0 * d0).sum(1), (d0 * d1).sum(1), (d1 * d1).sum(1)
+        d20, d21 = (d2 * d0).sum(1), (d2 * d1).sum(1)
+        denom = d00 * d11 - d01 * d01
+        v = (d11 * d20 - d01 * d21) / denom
+        w = (d00 * d21 - d01 * d20) / denom
+        u = 1.0 - v - w
+        acc = ~(np.abs(cosine) < 1e-8) & ~((time < 1e-12)) & (u >= 0) & (v >= 0) & (w >= 0)
+    return acc, time
+
+
+def check(tris, o, d, lo, hi, what):
+    q, scale, lo, full = quantise(tris, lo, hi)
+    acc, time = exact_hit(tris, o, d)
+    assert acc.sum() > 0.1 * len(acc), (what, acc.mean())  # rays aimed at a vertex hit it ~1 time in 5
+    for t_lo, t_hi in ((1e-12, np.inf), (time, time), (np.nextafter(time, -np.inf), np.nextafter(time, np.inf))):
+        ok, on = box_pass(q, scale, lo, o, d, t_lo, t_hi)
+        bad = acc & ~ok
+        assert not bad.any(), (what, int(bad.sum()), np.flatnonzero(bad)[:5])
+    return on.mean(), full.mean()
+
+
+def aimed_rays(rs, tris, bary, dist_scale=1.0):
+    """rays from random origins through the point with barycentrics `bary` of each triangle"""
+    v = tris.reshape(-1, 3, 3)
+    p = (bary[:, :, None] * v).sum(axis=1)
+    o = p + rs.randn(len(tris), 3) * dist_scale
+    d = p - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+def test_filter_never_rejects_an_accepted_hit_on_the_bench_mesh():
+    rows = scenes.knot_mesh(nu=392, nv=32)            # 25k triangles of the C3 stand-in's shape
+    tris = rows[:, :9]
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    rs = np.random.RandomState(1)
+    rep = np.repeat(tris, 40, axis=0)                 # 10^6 pairs per case
+    for what, bary in (("interior", rs.dirichlet((1, 1, 1), len(rep))),
+                       ("edges", np.stack([rs.rand(len(rep)), 1 - rs.rand(len(rep)) * 0 - 0, np.zeros(len(rep))], 1)),
+                       ("vertices", np.eye(3)[rs.randint(0, 3, len(rep))])):
+        if what == "edges":
+            a = rs.rand(len(rep))
+            bary = np.stack([a, 1.0 - a, np.zeros(len(rep))], axis=1)[:, rs.permutation(3)]
+        for dist in (0.05, 1.0, 50.0):
+            o, d = aimed_rays(rs, rep, bary, dist)
+            on, full = check(rep, o, d, lo, hi, (what, dist))
+            assert on > 0.99 and full == 0.0
+
+
+def test_filter_with_axis_parallel_rays_far_origins_and_corner_triangles():
+    rs = np.random.RandomState(2)
+    n = 400000
+    lo, hi = np.array([-3.0, 0.5, 10.0]), np.array([5.0, 0.75, 4000.0])      # anisotropic bounds, off-centre
+    c = lo + rs.rand(n, 3) * (hi - lo)
+    tris = (c[:, None, :] + rs.randn(n, 3, 3) * (hi - lo) * 10.0 ** rs.uniform(-4, -1, (n, 1, 1))).reshape(n, 9)
+    tris = np.clip(tris.reshape(n, 3, 3), lo, hi).reshape(n, 9)                # some flattened onto the bounds' faces
+    bary = rs.dirichlet((1, 1, 1), n)
+    o, d = aimed_rays(rs, tris, bary, 3.0)
+    check(tris, o, d, lo, hi, "anisotropic")
+    # nearly axis-parallel directions: huge slab parameters on two axes
+    p = (bary[:, :, None] * tris.reshape(n, 3, 3)).sum(1)
+    axis = rs.randint(0, 3, n)
+    d = rs.randn(n, 3) * 1e-9
+    d[np.arange(n), axis] = rs.choice([-1.0, 1.0], n)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = p - d * rs.uniform(0.1, 100.0, (n, 1))
+    check(tris, o, d, lo, hi, "axis-parallel")
+    # origins up to 10^7 extents away (beyond 10^10 grid steps the filter switches itself off)
+    o, d = aimed_rays(rs, tris, bary, 1.0)
+    far = 10.0 ** rs.uniform(0, 7, (n, 1)) * np.linalg.norm(hi - lo)
+    o = p - d * far
+    on, _ = check(tris, o, d, lo, hi, "far origins")
+    assert 0.1 < on < 1.0
+
+
+def test_slivers_are_never_filtered():
+    rs = np.random.RandomState(3)
+    n = 100000
+    a = rs.randn(n, 3)
+    e = rs.randn(n, 3)
+    tris = np.concatenate([a, a + e, a + e * rs.uniform(0.2, 0.8, (n, 1)) + rs.randn(n, 3) * 1e-7], axis=1)   # sin < 1e-5
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    q, scale, _, full = quantise(tris, lo, hi)
+    assert full.mean() > 0.99 and (q[full, 0:3] == 0).all() and (q[full, 3:6] == 65535).all()
+    degenerate = np.concatenate([a, a, a + e], axis=1)     # zero area: denom == 0
+    _, _, _, full = quantise(degenerate, lo, hi)
+    assert full.all()
