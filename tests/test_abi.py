@@ -62,14 +62,20 @@ def test_unsupported_shapes_rejected_at_scene_create_without_gpu():
         rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_UNIMPLEMENTED_SAMPLE  # plane.rs:34-36 unimplemented!()
 
+    # a group inside a group is in the closed set (one level, kdtree.rs:14-24); a third level is not
     scene = rpt_amd.Scene()
     inner = rpt_amd.KdTree([rpt_amd.sphere().translate((0, 0, 0))])
     scene.add(rpt_amd.Object(rpt_amd.KdTree([inner, rpt_amd.sphere()])))
     with pytest.raises(rpt_amd.RptGpuError) as e:
         rpt_amd.GpuScene(scene)
+    assert e.value.code == _abi.RPTGPU_E_NO_DEVICE   # flattening succeeded; only the device is missing here
+    scene = rpt_amd.Scene()
+    scene.add(rpt_amd.Object(rpt_amd.KdTree([rpt_amd.KdTree([inner, rpt_amd.cube()]), rpt_amd.sphere()])))
+    with pytest.raises(rpt_amd.RptGpuError) as e:
+        rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
 
-    scene = rpt_amd.Scene()  # MonomialSurface: only exp = 4 (monomial_surface.rs:10), not inside a KdTree group
+    scene = rpt_amd.Scene()  # MonomialSurface: only exp = 4 (monomial_surface.rs:10), at top level or as a tree child
     scene.add(rpt_amd.Object(rpt_amd.monomial_surface(1.0, 3.0)))
     with pytest.raises(rpt_amd.RptGpuError) as e:
         rpt_amd.GpuScene(scene)
@@ -78,7 +84,7 @@ def test_unsupported_shapes_rejected_at_scene_create_without_gpu():
     scene.add(rpt_amd.Object(rpt_amd.KdTree([rpt_amd.monomial_surface(1.0, 4.0), rpt_amd.sphere()])))
     with pytest.raises(rpt_amd.RptGpuError) as e:
         rpt_amd.GpuScene(scene)
-    assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
+    assert e.value.code == _abi.RPTGPU_E_NO_DEVICE
     with pytest.raises(rpt_amd.RptGpuError):
         rpt_amd.KdTree([rpt_amd.plane((0, 1, 0), 0.0), rpt_amd.sphere()]).lower([])
 
