@@ -4,7 +4,7 @@ TAG=$1; CTRS=$2; ARGS=$3
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace -d $OUT -o bench -- python $REPO/bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline $ARGS > $OUT/log.txt 2>&1
+timeout -k 5 240 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT -o bench -- python $REPO/bench.py --steps 1 --warmup 0 --spp 4 --no-cpu-baseline $ARGS > $OUT/log.txt 2>&1
 python - <<PY
 import re, sqlite3
 c = sqlite3.connect("$OUT/bench_results.db")
