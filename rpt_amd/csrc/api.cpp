@@ -228,18 +228,31 @@ struct Bracket {
 struct QueryMarks {
   rptgpu_scene* h;
   bool on;
-  Bracket* open[RPT_K_COUNT] = {};
+  int e0[RPT_K_COUNT];
+  QueryMarks(rptgpu_scene* h_, bool on_) : h(h_), on(on_) {
+    for (int& e : e0) e = -1;
+  }
 };
 void query_mark(void* ctx, int kind, int end) {
   QueryMarks* q = (QueryMarks*)ctx;
   if (kind < 0 || kind >= RPT_K_COUNT) return;
+  rptgpu_scene* h = q->h;
   if (!end) {
-    delete q->open[kind];
-    q->open[kind] = new Bracket(q->h, kind, q->on);
-  } else if (q->open[kind]) {
-    q->open[kind]->done();
-    delete q->open[kind];
-    q->open[kind] = nullptr;
+    h->stats.kernel_launches[kind]++;
+    q->e0[kind] = -1;
+    if (!q->on || h->ev_used + 2 > MAX_EVENT_PAIRS * 2) return;
+    while ((int)h->ev_pool.size() < h->ev_used + 2) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      h->ev_pool.push_back(e);
+    }
+    q->e0[kind] = h->ev_used;
+    h->ev_used += 2;
+    HIP_TRY(hipEventRecord(h->ev_pool[q->e0[kind]], h->stream));
+  } else if (q->e0[kind] >= 0) {
+    HIP_TRY(hipEventRecord(h->ev_pool[q->e0[kind] + 1], h->stream));
+    h->pending.push_back({kind, q->e0[kind], q->e0[kind] + 1});
+    q->e0[kind] = -1;
   }
 }
 
@@ -459,7 +472,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
       rptdev::Camera cam = make_camera(*camera);
       const bool any_lights = h->dscene.num_lights > 0;
-      QueryMarks qm{h, prof};
+      QueryMarks qm(h, prof);
       const QueryHook qhook{query_mark, &qm};
 
       for (uint32_t s0 = 0; s0 < p->iterations; s0 += s_chunk) {

@@ -185,6 +185,23 @@ def test_per_tree_queries_and_ray_sorting_do_not_change_the_image(name, sort, mo
     assert (img == load(name)["image"]).all()
 
 
+@pytest.mark.parametrize("knobs", [{"RPTGPU_LEAF_BOXES": "0"}, {"RPTGPU_MESH_PAIRS": "1"},
+                                   {"RPTGPU_MESH_PAIRS": "1", "RPTGPU_LEAF_BOXES": "0", "RPTGPU_SORT_RAYS": "1"}])
+@pytest.mark.parametrize("name", ["dragon", "wine_glass", "coverage", "fractal_spheres", "fractal_teapots", "nested_groups"])
+def test_leaf_box_filter_and_cooperative_leaves_are_scheduling_only(name, knobs, monkeypatch):
+    # the conservative box filter switched off, and the wave-cooperative leaf kernel (rpt_mesh_trace) switched on, with
+    # every tree sent through the per-tree kernels: the same image as the fixture
+    monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "1")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    scene, cam, p = small_scenes.small(name)
+    g = GpuScene(scene, 0)
+    for flags in (_abi.RPT_FLAG_WAVEFRONT, 0):
+        img = g.render_batch(cam, make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=flags))
+        assert (img == load(name)["image"]).all(), (name, knobs, flags)
+    g.close()
+
+
 def test_c1_full_config_bit_equal_to_oracle(oracle):
     # BASELINE configs[0]: examples/sphere.rs, 960x540, 2 bounces, 100 spp — in full
     scene, cam, cfg = scenes.sphere_scene()
