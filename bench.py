@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=None, help="spp of the CPU-baseline sample (default: ~15 s of CPU work)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last step's reduced f32 frame (.npy)")
     ap.add_argument("--fixed-samples", action="store_true", help="every step renders the same samples (tests)")
+    ap.add_argument("--emulate-part-of", type=int, default=0, metavar="N",
+                    help="single process: render only the tiles rank 0 would own among N ranks (no collective) and report "
+                         "the step time, i.e. the per-rank cost that bounds N-GPU scaling; the JSON line is NOT a bench result")
     ap.add_argument("--pmc-json", default=None, help="rocprofv3 PMC summary of this workload (default: profiles/<latest>_<scene>_pmc.json)")
     args = ap.parse_args()
 
@@ -169,6 +172,30 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.emulate_part_of > 1 and world == 1:
+        out32 = host_np
+
+        def step():  # noqa: F811 — what one of N ranks does between the collectives
+            p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=step_no[0] * spp, precision=precision,
+                            flags=_abi.RPT_FLAG_PROFILE_KERNELS | pipe_flag, tile=(32, 8), part=(0, args.emulate_part_of))
+            cam = camera.lower()
+            import ctypes as C
+            _abi.check(gpu.lib.rptgpu_render_batch_device(gpu.handle, C.byref(cam), C.byref(p), C.c_void_p(dframe.data_ptr()), 1, None), gpu.handle)
+            step_no[0] += 1
+        dframe = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps * 1e3
+        print(json.dumps({"emulated": "rank 0 of %d" % args.emulate_part_of, "scene": args.scene, "spp": spp, "ms_per_step_of_this_rank": dt,
+                          "note": "per-rank render time without the reduce; compare with ms_per_step at N=1 divided by N"}))
+        gpu.close()
+        return
 
     for _ in range(args.warmup):
         step()
