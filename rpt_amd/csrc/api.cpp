@@ -524,6 +524,15 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         HIP_TRY(hipGetLastError()); // a failed launch is reported here, not by the stream sync
       }
       kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
+      if (std::getenv("RPTGPU_PRINT_PHASES")) { // only with a -DRPT_TT_TIMERS build
+        HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long ph[8];
+        if (kt->read_tt_phases(ph)) {
+          const char* nm[6] = {"refill", "node steps", "leaf (boxes + exact)", "pop", "write-out", "  of which exact tests"};
+          unsigned long long tot = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
+          for (int i = 0; i < 6 && tot; i++) std::fprintf(stderr, "tree_trace phase %-24s %6.2f %%\n", nm[i], 100.0 * ph[i] / tot);
+        }
+      }
     }
     HIP_TRY(hipGetLastError());
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, frame_elems * out_elem, hipMemcpyDeviceToHost, st));

@@ -70,6 +70,8 @@ struct KernelTable {
                        const double* thr, uint8_t* out);
   void (*buffer_variance)(hipStream_t, const double* total, const double* const* batches, uint32_t nb, uint64_t npix,
                           double* out);
+  // -DRPT_TT_TIMERS builds: per-phase wave cycles of rpt_tree_trace since the last call; false in regular builds
+  bool (*read_tt_phases)(unsigned long long out[8]);
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)
