@@ -535,3 +535,34 @@ impl Drop for GpuScene {
         unsafe { ffi::rptgpu_scene_destroy(self.h) }
     }
 }
+
+#[cfg(test)]
+mod layout_tests {
+    //! `cargo test` in this crate re-checks what tests/test_rust_layout.py of the back-end repository checks from the
+    //! outside: the sizes of the `#[repr(C)]` structs are those of the C structs (x86-64 / LP64; values from gcc via
+    //! tests/test_abi.py), and the library this crate links to speaks the same ABI version.
+    use super::ffi::*;
+    use std::mem::size_of;
+
+    #[test]
+    fn struct_sizes_match_rpt_gpu_h() {
+        assert_eq!(size_of::<RptMaterial>(), 64);
+        assert_eq!(size_of::<RptTriangle>(), 144);
+        assert_eq!(size_of::<RptTransform>(), 408);
+        assert_eq!(size_of::<RptShape>(), 496);
+        assert_eq!(size_of::<RptObject>(), 560);
+        assert_eq!(size_of::<RptLight>(), 616);
+        assert_eq!(size_of::<RptEnvironment>(), 48);
+        assert_eq!(size_of::<RptScene>(), 80);
+        assert_eq!(size_of::<RptCamera>(), 96);
+        assert_eq!(size_of::<RptRenderParams>(), 64);
+        assert_eq!(size_of::<RptStats>(), 160);
+        assert_eq!(size_of::<RptKdTree>(), 64);
+    }
+
+    #[test]
+    fn abi_version_matches_the_library() {
+        // SAFETY: plain query
+        assert_eq!(unsafe { rptgpu_abi_version() }, RPTGPU_ABI_VERSION);
+    }
+}

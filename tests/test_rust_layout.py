@@ -189,3 +189,13 @@ def test_philox_stream_of_the_patch_is_the_oracles(oracle):
         o = philox([pixel, sample & M, sample >> 32, draw >> 1], [seed & M, seed >> 32])
         want = (o[3] << 32 | o[2]) if draw & 1 else (o[1] << 32 | o[0])
         assert oracle.lib().oracle_rng_u64(seed, pixel, sample, draw) == want
+
+
+def test_struct_sizes_in_the_crates_own_tests_are_the_c_sizes():
+    import ctypes as C
+    from rpt_amd import _abi
+    rs = open(RUST).read()
+    found = dict(re.findall(r"assert_eq!\(size_of::<(\w+)>\(\), (\d+)\);", rs))
+    assert len(found) >= 12
+    for name, size in found.items():
+        assert C.sizeof(getattr(_abi, name)) == int(size), name
