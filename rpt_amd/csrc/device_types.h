@@ -15,9 +15,9 @@ namespace rptdev {
 constexpr int KD_MAX_STACK = 32; // deepest kd-tree the traversal stack holds
 constexpr int KD_LDS_LEVELS = 12;   // stack levels the persistent kernel keeps in LDS (rest: scratch)
 #ifndef RPT_KD_LDS_LEVELS_WF
-#define RPT_KD_LDS_LEVELS_WF 7
+#define RPT_KD_LDS_LEVELS_WF 10
 #endif
-constexpr int KD_LDS_LEVELS_WF = RPT_KD_LDS_LEVELS_WF; // same for the wavefront kernels (16 waves/CU share 160 KB)
+constexpr int KD_LDS_LEVELS_WF = RPT_KD_LDS_LEVELS_WF; // same for the wavefront kernels (3 blocks of 256 threads per CU share 160 KB)
 
 // One kd node: 16 B, one dwordx4 load.  Inner: a = left child (right = a+1), ib = axis (0..2).
 // Leaf: a = first entry in refs[], ib = 3 | (count << 2).
