@@ -1,17 +1,20 @@
 #!/bin/bash
-# final evidence of round 2: default bench line + rocprofv3 trace / PMC of C2 at its own spp, the same for the C3 stand-in,
-# bench lines of every BASELINE config at its real frame size with CPU baselines
+# final evidence of round 2: rocprofv3 trace + PMC of the bench command per scene (C2 at its own 512 spp), summarised on
+# the box (the rocpd databases do not travel: 64 MiB limit), and bench lines of every BASELINE config at its real frame size
+#   bash scripts/gpu_round2_final.sh ["scene:trace_spp:pmc_spp ..."]
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 O=gpurun_out/r02final; mkdir -p $O
-# the rocpd databases are summarised here, on the box, and deleted: only the summaries travel back (64 MiB limit)
 export RPT_PROFILE_DST=$REPO/$O/profiles
 mkdir -p $RPT_PROFILE_DST
-prof() { bash scripts/profile.sh r02 $1 $2 $3 > $O/profile_$1.log 2>&1; python scripts/summarize_profile.py r02 $1 > $O/summary_$1.txt 2>&1; rm -rf gpurun_out/prof_r02_$1; }
-prof cornell 0 512
-prof dragon 64 16
-prof wine_glass 16 4
-prof fractal_spheres 16 4
+LIST=${1:-"cornell:0:512 dragon:64:16 wine_glass:16:4 fractal_spheres:16:4 sphere:100:100 glass:64:64 room23:128:128"}
+for item in $LIST; do
+  IFS=: read sc tspp pspp <<< "$item"
+  bash scripts/profile.sh r02 $sc $tspp $pspp > $O/profile_$sc.log 2>&1
+  python scripts/summarize_profile.py r02 $sc > $O/summary_$sc.txt 2>&1
+  rm -rf gpurun_out/prof_r02_$sc
+done
+rm -f $O/other_configs.jsonl
 for cfg in "sphere 100" "dragon 256" "fractal_spheres 64" "glass 64" "wine_glass 64" "room23 128"; do
   set -- $cfg
   timeout 400 python bench.py --scene $1 --spp $2 --steps 2 2>$O/bench_$1.err | tail -1 >> $O/other_configs.jsonl
