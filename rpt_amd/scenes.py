@@ -184,13 +184,14 @@ def synthetic_hdri(width=2048, height=1024, seed=0xBA11):
 
 
 # ----------------------------------------------------------------------------- C3
-def dragon(nu=784, nv=64):
+def dragon(nu=784, nv=64, shape=None):
     """examples/dragon.rs:30-71 with the knot stand-in for dragon.obj —
-    BASELINE: 1920x1080, 8 bounces, 256 spp."""
+    BASELINE: 1920x1080, 8 bounces, 256 spp.  `shape`: an already placed shape to use instead of the stand-in
+    (SURVEY §8d names pegasus.obj, scaled x2 and dropped onto y = -1, as the alternative)."""
     scene = Scene()
-    mesh = Mesh(knot_mesh(nu, nv))
-    scene.add(Object(mesh.scale((3.4, 3.4, 3.4)).rotate_y(math.pi / 2.0))
-              .material(Material.specular(hex_color(0xB7CA79), 0.1)))
+    if shape is None:
+        shape = Mesh(knot_mesh(nu, nv)).scale((3.4, 3.4, 3.4)).rotate_y(math.pi / 2.0)
+    scene.add(Object(shape).material(Material.specular(hex_color(0xB7CA79), 0.1)))
     scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0xAAAAAA))))
     scene.add(Light.Ambient((0.01, 0.01, 0.01)))
     scene.add(Light.Object(Object(sphere().scale((2.0, 2.0, 2.0)).translate((0.0, 20.0, 3.0)))
@@ -289,12 +290,12 @@ def glass(hdri_size=(2048, 1024)):
     return scene, Camera(), dict(width=3840, height=2160, max_bounces=16, num_samples=4096)
 
 
-def wine_glass(hdri_size=(2048, 1024), segments=128):
-    """examples/wine_glass.rs:27-85 with the lathed stand-in for wine_glass.obj —
+def wine_glass(hdri_size=(2048, 1024), segments=128, mesh=None):
+    """examples/wine_glass.rs:27-85 with the lathed stand-in for wine_glass.obj (or `mesh`, e.g. the loaded asset) —
     BASELINE: 3840x2160, 16 bounces, 4096 spp."""
     scene = Scene()
     scene.environment = Environment.Hdri(synthetic_hdri(*hdri_size))
-    scene.add(Object(Mesh(lathe_glass_mesh(segments))).material(Material.clear(1.5, 0.0001)))
+    scene.add(Object(mesh if mesh is not None else Mesh(lathe_glass_mesh(segments))).material(Material.clear(1.5, 0.0001)))
     scene.add(Object(polygon([(-5.0, 0.0, -5.0), (-5.0, 0.0, 5.0), (5.0, 0.0, 5.0), (5.0, 0.0, -5.0)]))
               .material(Material.diffuse(hex_color(0x6F5D48))))
     scene.add(Light.Object(Object(sphere().scale((3.0, 3.0, 3.0)).translate((11.15, 13.739, -4.9325)))
@@ -371,6 +372,137 @@ def compound():
     return scene, camera, dict(width=1024, height=1024, max_bounces=5, num_samples=50)
 
 
+# ----------------------------------------------------------------------------- the asset-driven examples
+# The reference reads these files from its own examples/ directory; they are not redistributed here.  `asset(name)`
+# finds them in the directories of $RPT_ASSETS (os.pathsep-separated); every scene below takes the loaded mesh as an
+# argument and falls back to a seeded procedural stand-in of about the same size and extent.
+def asset(name):
+    """path of an asset file of the reference's examples/ (or of `name` inside pegasus.zip -> an open text file), or None"""
+    import os
+    for d in os.environ.get("RPT_ASSETS", "").split(os.pathsep):
+        if d and os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+def load_asset(name):
+    """the Mesh of an asset: *.obj, *.stl, or `pegasus.obj` out of pegasus.zip (examples/pegasus.rs:17-32); None if absent"""
+    from . import io
+    path = asset(name)
+    if path is not None:
+        return io.load_stl(path) if name.endswith(".stl") else io.load_obj(path)
+    if name == "pegasus.obj" and asset("pegasus.zip") is not None:
+        import io as _io
+        import zipfile
+        with zipfile.ZipFile(asset("pegasus.zip")) as z, z.open("pegasus.obj") as f:
+            return io.load_obj(_io.TextIOWrapper(f, encoding="utf-8", errors="replace"))
+    return None
+
+
+def _cylinder_stand_in(n=42):
+    """a capped cylinder with face normals in the frame of cylinder.stl (x, y in [0, 30], z in [0, 50])"""
+    a = np.linspace(0.0, 2.0 * math.pi, n, endpoint=False)
+    ring = np.stack([15.0 + 15.0 * np.cos(a), 15.0 + 15.0 * np.sin(a)], axis=1)
+    tris = []
+    for i in range(n):
+        p, q = ring[i], ring[(i + 1) % n]
+        b0, b1, t0, t1 = (p[0], p[1], 0.0), (q[0], q[1], 0.0), (p[0], p[1], 50.0), (q[0], q[1], 50.0)
+        tris += [(b0, b1, t1), (b0, t1, t0), ((15.0, 15.0, 0.0), b1, b0), ((15.0, 15.0, 50.0), t0, t1)]
+    from .shape import Triangle
+    return Mesh([Triangle.from_vertices(*t) for t in tris])
+
+
+def teapot(mesh=None):
+    """examples/teapot.rs:8-35 (a rough red metal teapot on a plane; the Renderer defaults: 0 bounces, 1 sample)."""
+    if mesh is None:
+        mesh = Mesh(_teapot_stand_in(48, 8))
+    scene = Scene()
+    scene.add(Object(mesh.scale((0.5, 0.5, 0.5)).translate((0.0, -1.0, 0.0)))
+              .material(Material.metallic_(hex_color(0xFF0000), 0.4)))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0xAAAAAA))))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    scene.add(Light.Point((60.0, 60.0, 60.0), (0.0, 5.0, 5.0)))
+    return scene, Camera(), dict(width=800, height=800, max_bounces=0, num_samples=1)
+
+
+def cylinder(mesh=None):
+    """examples/cylinder.rs:8-37 (an STL cylinder with the default material; point + directional light)."""
+    if mesh is None:
+        mesh = _cylinder_stand_in()
+    scene = Scene()
+    scene.add(Object(mesh.translate((-15.0, -15.0, -25.0)).scale((1.0 / 15.0, 1.0 / 15.0, 1.0 / 25.0))
+                     .rotate_y(math.pi / 4.0)))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0xAAAAAA))))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    scene.add(Light.Point((80.0, 80.0, 80.0), (0.0, 5.0, 5.0)))
+    n = math.sqrt((1.0 * 1.0 + 1.0 * 1.0) + 0.0 * 0.0)
+    scene.add(Light.Directional((2.0, 2.0, 2.0), (1.0 / n, -1.0 / n, 0.0 / n)))
+    return scene, Camera(), dict(width=512, height=512, max_bounces=0, num_samples=1)
+
+
+def rustacean(mesh=None):
+    """examples/rustacean.rs:9-72 (Ferris with three glass and three metal eyes-on-stalks beads under a sphere lamp)."""
+    if mesh is None:
+        rows = knot_mesh(196, 32, seed=0xFE2215)   # 25 088 triangles; the asset has 25 296
+        rows[:, :9] *= 1.2
+        mesh = Mesh(rows).translate((0.0, 0.45, 0.0))
+    cs = (2.0, 2.4, 2.0)
+    scene = Scene()
+    scene.add(Object(mesh.translate((0.0, 0.134649, 0.0)).scale(cs)).material(Material.specular(hex_color(0xF84C00), 0.2)))
+    scene.add(Object(plane((0.0, 1.0, 0.0), 0.0)).material(Material.diffuse(hex_color(0xAAAA77))))
+    balls = [(True, 0.2, (-0.81, 1.02, 0.47)), (True, 0.3, (-0.86, 1.10, 0.36)), (True, 0.4, (-0.75, 1.12, 0.34)),
+             (False, 0.2, (0.87, 1.03, 0.41)), (False, 0.3, (0.75, 1.09, 0.36)), (False, 0.4, (0.85, 1.15, 0.45))]
+    for is_glass, roughness, pos in balls:
+        pos = (cs[0] * pos[0], cs[1] * pos[1], cs[2] * pos[2])
+        scene.add(Object(sphere().scale((0.1, 0.1, 0.1)).translate(pos))
+                  .material(Material.clear(1.5, roughness) if is_glass else Material.metallic_(hex_color(0xFFFFFF), roughness)))
+    scene.add(Light.Object(Object(sphere().scale((2.0, 2.0, 2.0)).translate((0.0, 20.0, 3.0)))
+                           .material(Material.light((1.0, 1.0, 1.0), 160.0))))
+    camera = Camera.look_at((-2.5, 4.0, 8.5), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), math.pi / 6.0)
+    return scene, camera, dict(width=800, height=800, max_bounces=4, num_samples=10)
+
+
+def pegasus(mesh=None, hdri_size=(2048, 1024)):
+    """examples/pegasus.rs:51-100 (an ice sculpture: rough transparent 100k-triangle mesh over a quad, HDRI only, EV -1.5)."""
+    if mesh is None:
+        rows = knot_mesh(784, 64, seed=0x9E6A)     # 100 352 triangles; pegasus.obj has 100 138
+        rows[:, :9] *= 0.55
+        mesh = Mesh(rows).translate((0.0, 0.72, 0.0))
+    scene = Scene()
+    scene.environment = Environment.Hdri(synthetic_hdri(*hdri_size))
+    scene.add(Object(mesh.scale((1.4, 1.4, 1.4))).material(Material.transparent_(hex_color(0xF8F8FF), 1.31, 0.2)))
+    scene.add(Object(polygon([(2.0, -0.01, 2.0), (2.0, -0.01, -2.0), (-2.0, -0.01, -2.0), (-2.0, -0.01, 2.0)]))
+              .material(Material.diffuse(hex_color(0xDDDDDD))))
+    camera = Camera.look_at((0.0, 1.5, 3.1), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), math.pi / 4.0)
+    return scene, camera, dict(width=1200, height=1200, max_bounces=8, num_samples=10, exposure_value=-1.5)
+
+
+def metal(mesh=None, hdri_size=(2048, 1024)):
+    """examples/metal.rs:30-63 (two instances of ONE Arc<Mesh>: a mirror teapot and one of roughness 0.1, HDRI only)."""
+    if mesh is None:
+        mesh = Mesh(_teapot_stand_in(48, 8))
+    scene = Scene()
+    scene.environment = Environment.Hdri(synthetic_hdri(*hdri_size))
+    scene.add(Object(mesh.scale((0.5, 0.5, 0.5)).translate((0.0, -1.7, 0.0))).material(Material.metallic_(hex_color(0xFFFFFF), 0.1)))
+    scene.add(Object(mesh.scale((0.5, 0.5, 0.5)).translate((0.0, 0.2, 0.0))).material(Material.metallic_(hex_color(0xFFFFFF), 0.0001)))
+    return scene, Camera(), dict(width=1200, height=900, max_bounces=5, num_samples=20)
+
+
+def simple_video(frame=0):
+    """examples/simple_video.rs:10-56, frame `frame` of 60: basic.rs's scene with the cube sliding away; the example
+    rebuilds the scene and the Renderer for every frame, which is what scene_create + render_batch per frame is."""
+    scene = Scene()
+    scene.add(Object(sphere()))
+    scene.add(Object(cube().rotate_y(math.pi / 6.0).scale((0.5, 0.3, 0.4)).translate((0.4, -0.8, 4.0 + 0.01 * float(frame))))
+              .material(Material.specular(hex_color(0xFF00FF), 0.5)))
+    scene.add(Object(sphere().scale((0.5, 0.5, 0.5)).translate((1.5, -0.5, 1.0))).material(Material.specular(hex_color(0x0000FF), 0.1)))
+    scene.add(Object(sphere().scale((0.5, 0.5, 0.5)).translate((-1.5, -0.5, 1.0))).material(Material.specular(hex_color(0x00FF00), 0.1)))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.specular(hex_color(0xAAAAAA), 0.5)))
+    scene.add(Light.Ambient((0.01, 0.01, 0.01)))
+    scene.add(Light.Point((100.0, 100.0, 100.0), (0.0, 5.0, 5.0)))
+    return scene, Camera(), dict(width=800, height=600, max_bounces=1, num_samples=100)
+
+
 # ----------------------------------------------------------------------------- a flat scene that is not Cornell
 def polygon_room(n_walls=23, transformed_every=0, sides=(4, 5, 6, 8), seed=3):
     """Many small polygon meshes in a row (single-leaf trees), optionally with a Transformed one every few
@@ -405,4 +537,6 @@ def polygon_room(n_walls=23, transformed_every=0, sides=(4, 5, 6, 8), seed=3):
 
 SCENES = {"room23": polygon_room, "sphere": sphere_scene, "cornell": cornell, "dragon": dragon,
           "fractal_spheres": fractal_spheres, "glass": glass, "wine_glass": wine_glass,
-          "fractal_teapots": fractal_teapots, "basic": basic, "monomial_glass": monomial_glass, "spheres": spheres, "compound": compound}
+          "fractal_teapots": fractal_teapots, "basic": basic, "monomial_glass": monomial_glass, "spheres": spheres, "compound": compound,
+          "teapot": teapot, "cylinder": cylinder, "rustacean": rustacean, "pegasus": pegasus, "metal": metal,
+          "simple_video": simple_video}

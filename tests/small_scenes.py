@@ -142,6 +142,29 @@ def small(name):
     if name == "nested_groups":
         s, c = nested_groups()
         return s, c, make_params(64, 40, 4, 4, seed=114)
+    # the asset-driven examples with small stand-ins for their assets
+    if name == "teapot":
+        s, c, d = scenes.teapot(mesh=Mesh(scenes._teapot_stand_in(24, 6)))
+        return s, c, make_params(48, 48, 3, 4, seed=115)     # the example itself renders with 0 bounces
+    if name == "cylinder":
+        s, c, d = scenes.cylinder(mesh=scenes._cylinder_stand_in(12))
+        return s, c, make_params(48, 48, 2, 4, seed=116)
+    if name == "rustacean":
+        rows = scenes.knot_mesh(48, 8, seed=0xFE2215)
+        rows[:, :9] *= 1.2
+        s, c, d = scenes.rustacean(mesh=Mesh(rows).translate((0.0, 0.45, 0.0)))
+        return s, c, make_params(64, 64, 4, 4, seed=117)
+    if name == "pegasus":
+        rows = scenes.knot_mesh(48, 8, seed=0x9E6A)
+        rows[:, :9] *= 0.55
+        s, c, d = scenes.pegasus(mesh=Mesh(rows).translate((0.0, 0.72, 0.0)), hdri_size=(128, 64))
+        return s, c, make_params(48, 48, 8, 4, seed=118, exposure_value=d["exposure_value"])
+    if name == "metal":
+        s, c, d = scenes.metal(mesh=Mesh(scenes._teapot_stand_in(24, 6)), hdri_size=(128, 64))
+        return s, c, make_params(64, 48, 5, 4, seed=119)
+    if name == "simple_video":
+        s, c, d = scenes.simple_video(frame=7)
+        return s, c, make_params(64, 48, 1, 4, seed=120)
     # the same scenes at 256x144 with 32 spp: ~10^6 samples each, so that draw sequences a 64x36 frame at 4 spp
     # hardly ever produces (long rejection loops, TIR, gen_range redraws, deep clamp chains) do occur
     if name == "cornell_hi":
@@ -155,4 +178,5 @@ def small(name):
 
 HI_NAMES = ["cornell_hi", "coverage_hi"]
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
-         "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots", "nested_groups"]
+         "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots", "nested_groups",
+         "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video"]

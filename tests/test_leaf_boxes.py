@@ -9,6 +9,7 @@ import numpy as np
 from rpt_amd import scenes
 
 GRID = 65529.0   # plus two steps of padding on either side of the bounds
+BOX_PAR = 1e280  # slab "slope" of an axis with d == 0 (shapes.inc)
 
 
 def quantise(tris, lo, hi):
@@ -34,11 +35,15 @@ def quantise(tris, lo, hi):
 def box_pass(q, scale, lo, o, d, t_lo, t_hi):
     """boxray_make + leaf_box_pass for pairs (q[i], ray i); returns (pass, filter_on)"""
     with np.errstate(all="ignore"):
+        z = d == 0                      # axes the ray does not move along: "is the origin inside the box on that axis"
         r = 1.0 / d
-        a = scale * r
-        b = (lo - o) * r
-        aa, am, bm = np.abs(a).min(axis=1), np.abs(a).max(axis=1), np.abs(b).max(axis=1)
-        on = (d != 0).all(axis=1) & (aa > 0) & (am < 1e150) & (bm < 1e150) & (bm < 1e10 * aa)
+        g = (o - lo) / scale
+        a = np.where(z, BOX_PAR, scale * r)
+        b = np.where(z, -g * BOX_PAR, (lo - o) * r)
+        aa = np.where(z, np.inf, np.abs(a)).min(axis=1)
+        am, bm = np.where(z, 0.0, np.abs(a)).max(axis=1), np.where(z, 0.0, np.abs(b)).max(axis=1)
+        par_ok = (~z | (np.abs(g) < 1e10)).all(axis=1)
+        on = ~z.all(axis=1) & par_ok & (aa > 0) & (am < 1e150) & (bm < 1e150) & (bm < 1e10 * aa)
         t0 = q[:, 0:3] * a + b   # the device uses fma: one rounding less
         t1 = q[:, 3:6] * a + b
         near, far = np.fmin(t0, t1), np.fmax(t0, t1)
@@ -125,6 +130,21 @@ def test_filter_with_axis_parallel_rays_far_origins_and_corner_triangles():
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     o = p - d * rs.uniform(0.1, 100.0, (n, 1))
     check(tris, o, d, lo, hi, "axis-parallel")
+    # EXACTLY axis-parallel directions (one or two components zero: shadow rays towards an axis-aligned directional
+    # light): the filter stays on, and passes whenever the exact test accepts
+    for nz in (1, 2):
+        d = rs.randn(n, 3)
+        for k in range(nz):
+            d[np.arange(n), (axis + k) % 3] = 0.0
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o = p - d * rs.uniform(0.1, 100.0, (n, 1))
+        o = np.where(d == 0, p, o)         # o + t d == p is then exact on the zero axes
+        on, _ = check(tris, o, d, lo, hi, "%d zero components" % nz)
+        assert on > 0.95
+        # and it does filter: against OTHER triangles (shifted by a tenth of the extent) almost nothing passes
+        q, scale, lo2, full = quantise(np.roll(tris, n // 2, axis=0), lo, hi)
+        ok, _ = box_pass(q, scale, lo2, o, d, 1e-12, np.inf)
+        assert ok.mean() < 0.2, ok.mean()
     # origins up to 10^7 extents away (beyond 10^10 grid steps the filter switches itself off)
     o, d = aimed_rays(rs, tris, bary, 1.0)
     far = 10.0 ** rs.uniform(0, 7, (n, 1)) * np.linalg.norm(hi - lo)
