@@ -137,6 +137,7 @@ struct rptgpu_scene {
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
   bool has_deep = false;
+  int rays_in_kernel = 0;          // RPTGPU_RAYS_IN_KERNEL: rptgpu_closest_hit keeps to rpt_extend_rays also when the scene has deep trees
   int mesh_pairs = 0;              // RPTGPU_MESH_PAIRS: wave-cooperative leaves for deep meshes (measured slower, off)
   DevBuf<uint32_t> tq, tq_ctr;
   // optional ray sort in front of the per-tree traversal (RPTGPU_SORT_RAYS)
@@ -307,8 +308,8 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   h->queue_b.alloc(cap);
   h->counters.alloc(4);
   if (h->has_deep) {
-    h->tq.alloc(cap);
-    h->tq_ctr.alloc(2);
+    h->tq.alloc(3 * cap); // a tree's ray queue | its rays with a zero direction component | those handed to the general form
+    h->tq_ctr.alloc(5);
     if (h->sort_rays) {
       h->sort_kin.alloc(cap); h->sort_kout.alloc(cap); h->sort_vin.alloc(cap);
       size_t bytes = rpt_strict::TABLE.sort_temp_bytes((uint32_t)cap);
@@ -450,7 +451,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       if (!target) {
         const uint64_t nl = (uint64_t)std::max(1, h->dscene.num_lights);
         uint64_t per_path = 6 * 8 + 4 * 8 + 4 + 4 + 1 + (uint64_t)(p->max_bounces + 1) * rptdev::REC_FIELDS * 8 +
-                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + (h->has_deep ? 4 + nl * 8 + (h->sort_rays ? 12 + 16 : 0) : 0);
+                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + (h->has_deep ? 12 + nl * 8 + (h->sort_rays ? 12 + 16 : 0) : 0);
         uint64_t budget = h->ws_budget_bytes;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -617,6 +618,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
     if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RPTGPU_MESH_PAIRS")) h->mesh_pairs = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("RPTGPU_RAYS_IN_KERNEL")) h->rays_in_kernel = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_RAYS")) h->sort_mode = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_MIN_BYTES")) h->sort_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
     for (int i = 0; i < fs.num_objects; i++) {
@@ -847,6 +849,40 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
   try {
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
+    if (h->has_deep && !h->rays_in_kernel) {
+      // a scene with deep trees: the rays take the route a render's rays take — object by object, every deep tree with
+      // its own queue, sort and persistent traversal (launch_query) — in pieces of at most 4 Mi rays
+      const KernelTable* kt = table_for(precision_mode, h->ext_shapes);
+      const uint64_t piece = std::min<uint64_t>(n, 4ull << 20);
+      ensure_workspace(h, piece, 0);
+      rptdev::PathState ps{};
+      ps.ray = h->ray.p; ps.hit = h->hit.p; ps.hit_obj = h->hit_obj.p; ps.draw = h->draw.p;
+      ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.shadow = h->shadow.p; ps.cap = h->ws_cap;
+      const uint32_t trace_blocks = (uint32_t)std::max(1, h->num_cus * 4);
+      std::vector<double> soa(6 * piece), hit(4 * piece);
+      for (uint64_t base = 0; base < n; base += piece) {
+        const uint64_t m = std::min(piece, n - base);
+        for (uint64_t i = 0; i < m; i++)
+          for (int k = 0; k < 3; k++) {
+            soa[(uint64_t)k * m + i] = origins[3 * (base + i) + k];
+            soa[(uint64_t)(3 + k) * m + i] = dirs[3 * (base + i) + k];
+          }
+        for (int k = 0; k < 6; k++)
+          HIP_TRY(hipMemcpyAsync(ps.ray + (uint64_t)k * ps.cap, soa.data() + (uint64_t)k * m, m * sizeof(double), hipMemcpyHostToDevice, st));
+        kt->query(st, h->dscene, ps, nullptr, (uint32_t)m, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
+                  h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, nullptr, h->mesh_pairs);
+        HIP_TRY(hipGetLastError());
+        for (int k = 0; k < 4; k++)
+          HIP_TRY(hipMemcpyAsync(hit.data() + (uint64_t)k * m, ps.hit + (uint64_t)k * ps.cap, m * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_object + base, ps.hit_obj, m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < m; i++) {
+          out_t[base + i] = hit[i];
+          for (int k = 0; k < 3; k++) out_normal[3 * (base + i) + k] = hit[(uint64_t)(1 + k) * m + i];
+        }
+      }
+      return RPTGPU_OK;
+    }
     DevBuf<double> d_o, d_d, d_t, d_n;
     DevBuf<int32_t> d_obj;
     d_o.alloc(3 * n); d_d.alloc(3 * n); d_t.alloc(n); d_n.alloc(3 * n); d_obj.alloc(n);

@@ -91,6 +91,26 @@ def nested_groups():
     return scene, camera
 
 
+def axis_sun():
+    """Directional lights along the axes and in a coordinate plane over an UNTRANSFORMED deep mesh, a group of spheres and
+    a plane: every shadow ray has one or two direction components that are exactly zero (the compact traversal's and the
+    leaf-box filter's special case, kernels/traversal.inc, shapes.inc)."""
+    scene = Scene()
+    rows = scenes.knot_mesh(96, 16, seed=0xA715)
+    rows[:, :9] *= 2.2
+    scene.add(Object(Mesh(rows)).material(Material.specular(hex_color(0xB7CA79), 0.3)))
+    kids = [sphere().scale((0.12, 0.12, 0.12)).translate((-2.0 + 0.4 * (i % 11), -0.9 + 0.35 * (i // 11), 1.6 - 0.2 * (i % 3)))
+            for i in range(66)]
+    scene.add(Object(KdTree(kids)).material(Material.diffuse(hex_color(0xCC7755))))
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.2)).material(Material.diffuse(hex_color(0xAAAAAA))))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    scene.add(Light.Directional((0.9, 0.9, 0.8), (0.0, -1.0, 0.0)))
+    scene.add(Light.Directional((0.3, 0.3, 0.5), (-1.0, -1.0, 0.0)))  # (exactly horizontal light would be 0/0 in bsdf on the plane)
+    scene.add(Light.Directional((0.4, 0.3, 0.3), (0.0, -0.6, -0.8)))
+    camera = Camera.look_at((1.5, 2.5, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.7)
+    return scene, camera
+
+
 def small(name):
     """-> (scene, camera, params) for the named small config."""
     if name == "sphere":
@@ -165,6 +185,9 @@ def small(name):
     if name == "simple_video":
         s, c, d = scenes.simple_video(frame=7)
         return s, c, make_params(64, 48, 1, 4, seed=120)
+    if name == "axis_sun":
+        s, c = axis_sun()
+        return s, c, make_params(64, 40, 4, 4, seed=121)
     # the same scenes at 256x144 with 32 spp: ~10^6 samples each, so that draw sequences a 64x36 frame at 4 spp
     # hardly ever produces (long rejection loops, TIR, gen_range redraws, deep clamp chains) do occur
     if name == "cornell_hi":
@@ -179,4 +202,4 @@ def small(name):
 HI_NAMES = ["cornell_hi", "coverage_hi"]
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
          "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots", "nested_groups",
-         "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video"]
+         "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video", "axis_sun"]

@@ -170,6 +170,56 @@ def test_high_sample_render_bit_equal_to_golden(name, pipeline):
     assert (img == ref).all(), "max |delta| = %g on %d pixels" % (np.abs(img - ref).max(), (img != ref).any(axis=1).sum())
 
 
+@pytest.mark.parametrize("route", ["per_tree", "per_tree_unsorted", "in_kernel", "default"])
+def test_axis_parallel_rays_and_origins_on_split_planes(oracle, route, monkeypatch):
+    """Rays with one or two direction components exactly zero — and, among them, origins that lie exactly ON a split
+    plane (or a face of the bounds) of an axis the ray does not move along, where the reference's (value - o) / d is
+    0/0 = NaN — through rptgpu_closest_hit: with every tree sent through rpt_tree_enter / rpt_tree_trace /
+    rpt_tree_general, with the in-kernel traversal (kd_intersect_fast and its restart in the general form), and with
+    the defaults.  Bit-equal to the oracle."""
+    from rpt_amd.device import kdtree_build
+    if route.startswith("per_tree"):
+        monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "1")
+        monkeypatch.setenv("RPTGPU_SORT_RAYS", "0" if route.endswith("unsorted") else "1")
+    if route == "in_kernel":
+        monkeypatch.setenv("RPTGPU_RAYS_IN_KERNEL", "1")
+    scene, cam = small_scenes.axis_sun()
+    rows = np.asarray(scene.objects[0].shape.triangles)
+    v = rows[:, :9].reshape(-1, 3, 3)
+    boxes = np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1)
+    tree = kdtree_build(boxes)
+    inner = np.flatnonzero((tree["info"] & 3) != 3)
+    assert len(inner) > 100 and tree["regular"] == 1
+    lo, hi = boxes[:, :3].min(axis=0), boxes[:, 3:].max(axis=0)
+    rs = np.random.RandomState(11)
+    n = 60000
+    o = lo + rs.rand(n, 3) * (hi - lo) * 1.2 - 0.1 * (hi - lo)
+    d = rs.randn(n, 3)
+    ax = rs.randint(0, 3, n)
+    d[np.arange(n), ax] = 0.0
+    two = rs.rand(n) < 0.3
+    d[np.arange(n)[two], (ax[two] + 1) % 3] = 0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # a third of the origins ON a split plane of their zero axis: the root's, or any inner node's of that axis
+    for i in range(0, n, 3):
+        cand = inner[(tree["info"][inner] & 3) == ax[i]]
+        node = 0 if ((tree["info"][0] & 3) == ax[i] and i % 2 == 0) else cand[rs.randint(len(cand))]
+        o[i, ax[i]] = tree["split"][node]
+    # and some ON the faces of the bounds (the root slab test's own 0/0)
+    for i in range(1, n, 30):
+        o[i, ax[i]] = (lo if i % 2 else hi)[ax[i]]
+    with np.errstate(all="ignore"):
+        assert np.isnan((tree["split"][0] - o[:, tree["info"][0] & 3]) / d[:, tree["info"][0] & 3]).sum() > 1000
+    g = GpuScene(scene, 0)
+    t0, n0, ob0 = oracle.OracleScene(scene).closest_hit(o, d)
+    t1, n1, ob1 = g.closest_hit(o, d)
+    g.close()
+    assert (ob0 == 0).sum() > 5000 and (ob0 == 1).sum() > 50
+    same_t = (t0.view(np.int64) == t1.view(np.int64)) | (np.isnan(t0) & np.isnan(t1))
+    assert same_t.all(), (route, int((~same_t).sum()), np.flatnonzero(~same_t)[:5])
+    assert (ob0 == ob1).all() and (n0.view(np.int64) == n1.view(np.int64)).all()
+
+
 @pytest.mark.parametrize("sort", ["0", "1"])
 @pytest.mark.parametrize("name", small_scenes.NAMES)
 def test_per_tree_queries_and_ray_sorting_do_not_change_the_image(name, sort, monkeypatch):

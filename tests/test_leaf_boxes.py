@@ -49,7 +49,7 @@ def box_pass(q, scale, lo, o, d, t_lo, t_hi):
         near, far = np.fmin(t0, t1), np.fmax(t0, t1)
         tl = np.fmax(np.fmax(near[:, 0], near[:, 1]), near[:, 2])
         th = np.fmin(np.fmin(far[:, 0], far[:, 1]), far[:, 2])
-        ok = (tl <= th) & (th >= t_lo) & (tl <= t_hi)
+        ok = (tl <= th) & ~(th < t_lo) & ~(tl > t_hi)   # a NaN bound (t_min below a 0/0 split) rejects nothing
     return ok | ~on, on
 
 
@@ -77,7 +77,8 @@ def check(tris, o, d, lo, hi, what):
     q, scale, lo, full = quantise(tris, lo, hi)
     acc, time = exact_hit(tris, o, d)
     assert acc.sum() > 0.1 * len(acc), (what, acc.mean())  # rays aimed at a vertex hit it ~1 time in 5
-    for t_lo, t_hi in ((1e-12, np.inf), (time, time), (np.nextafter(time, -np.inf), np.nextafter(time, np.inf))):
+    for t_lo, t_hi in ((1e-12, np.inf), (time, time), (np.nextafter(time, -np.inf), np.nextafter(time, np.inf)),
+                       (np.nan, np.nextafter(time, np.inf))):
         ok, on = box_pass(q, scale, lo, o, d, t_lo, t_hi)
         bad = acc & ~ok
         assert not bad.any(), (what, int(bad.sum()), np.flatnonzero(bad)[:5])
