@@ -12,6 +12,7 @@ for item in $LIST; do
   IFS=: read sc tspp pspp <<< "$item"
   bash scripts/profile.sh r02 $sc $tspp $pspp > $O/profile_$sc.log 2>&1
   python scripts/summarize_profile.py r02 $sc > $O/summary_$sc.txt 2>&1
+  cp $RPT_PROFILE_DST/r02_${sc}_pmc.json profiles/ 2>/dev/null   # the bench lines below quote THIS build's counters
   rm -rf gpurun_out/prof_r02_$sc
 done
 rm -f $O/other_configs.jsonl
