@@ -143,7 +143,7 @@ struct rptgpu_scene {
   // optional ray sort in front of the per-tree traversal (RPTGPU_SORT_RAYS)
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
   int sort_mode = -1;              // RPTGPU_SORT_RAYS: 0 never, 1 every deep tree, default: by footprint
-  uint64_t sort_min_bytes = 32ull << 20; // RPTGPU_SORT_MIN_BYTES: nodes + leaf records beyond the L2s
+  uint64_t sort_min_bytes = 8ull << 20;  // RPTGPU_SORT_MIN_BYTES: nodes + leaf records of a tree whose rays are worth sorting
   DevBuf<uint32_t> sort_kin, sort_kout, sort_vin;
   DevBuf<uint8_t> sort_tmp;
   SortBufs sort_bufs{};
@@ -625,8 +625,11 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       const rptdev::Inst& in = fs.insts[i];
       bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
       bool deep = tree && fs.tree_depth[in.tree] >= deep_depth;
-      // rays entering a tree whose nodes + leaf records do not fit the L2s are sorted by entry cell and
-      // octant first (C3 stand-in, 64 MB of leaf records: +12 %; a 16k-triangle glass in L2: -9 %, so not there)
+      // rays entering a large tree are sorted by entry cell and octant first: neighbours in a wave then walk the same
+      // nodes.  Measured with the VALU-bound traversal kernel of round 2: 100k-triangle mesh (66 MB of nodes + leaf
+      // records) 144 -> 172 Msamples/s, 16k-triangle glass (17 MB) 469 -> 528, a 25k-triangle mesh under few bounces
+      // (25 MB) 781 -> 766, two 768-triangle meshes (0.6 MB) 4243 -> 3248: the sort sorts EVERY ray of the depth, the
+      // gain grows with the work of the rays that enter — so by size, with the threshold well below the glass
       bool sort = false;
       if (deep) {
         const rptdev::Tree& tr = fs.trees[in.tree];

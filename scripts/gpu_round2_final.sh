@@ -1,7 +1,7 @@
 #!/bin/bash
 # final evidence of round 2: rocprofv3 trace + PMC of the bench command per scene (C2 at its own 512 spp), summarised on
 # the box (the rocpd databases do not travel: 64 MiB limit), and bench lines of every BASELINE config at its real frame size
-#   bash scripts/gpu_round2_final.sh ["scene:trace_spp:pmc_spp ..."]
+#   bash scripts/gpu_round2_final.sh ["scene:trace_spp:pmc_spp ..."] ["scene spp,scene spp,..."]
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 O=gpurun_out/r02final; mkdir -p $O
@@ -16,7 +16,8 @@ for item in $LIST; do
   rm -rf gpurun_out/prof_r02_$sc
 done
 rm -f $O/other_configs.jsonl
-for cfg in "sphere 100" "dragon 256" "fractal_spheres 64" "glass 64" "wine_glass 64" "room23 128"; do
+IFS=, read -ra CFGS <<< "${2:-sphere 100,dragon 256,fractal_spheres 64,glass 64,wine_glass 64,room23 128}"
+for cfg in "${CFGS[@]}"; do
   set -- $cfg
   timeout 400 python bench.py --scene $1 --spp $2 --steps 2 2>$O/bench_$1.err | tail -1 >> $O/other_configs.jsonl
 done
