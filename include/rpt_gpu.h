@@ -279,7 +279,9 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
 
 /* ---- the closest-hit kernel on its own: replaces Renderer::get_closest_hit
  * (renderer.rs:211-220) for a batch of rays (host arrays, n rays, xyz interleaved).
- * out_t = +inf and out_object = -1 on a miss. */
+ * out_t = +inf and out_object = -1 on a miss.  A scene with deep trees sends the rays the way a
+ * render does (object by object, per-tree queues, sort, persistent traversal); otherwise, or with
+ * RPTGPU_RAYS_IN_KERNEL=1, one kernel walks every object per ray.  Same results either way. */
 int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const double* dirs,
                        uint32_t precision_mode, double* out_t, double* out_normal,
                        int32_t* out_object);
