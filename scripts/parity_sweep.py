@@ -4,7 +4,7 @@ config at its FULL frame size, default pipeline and environment; the oracle (uni
 cores) renders 1/8 of the tiles at 16 spp, the GPU renders the same part; every pixel is compared bit for bit.
 The -m gpu tests do the same on 1/64..1/256 of the tiles at 2 spp; this is the same check on 60-250x more samples.
 
-    python scripts/parity_sweep.py [spp] [parts]
+    python scripts/parity_sweep.py [spp] [parts] [part] [seed]
 """
 import os
 import sys
@@ -19,13 +19,15 @@ from rpt_amd import GpuScene, make_params, scenes  # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+part = int(sys.argv[3]) if len(sys.argv) > 3 else 3 % parts
+seed0 = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0xABCDE
 L, how = O.baseline_lib(native=True)
-print("oracle build: %s; %d spp on 1/%d of the tiles" % (how, spp, parts))
+print("oracle build: %s; %d spp on part %d of %d of the tiles, seeds from %#x" % (how, spp, part, parts, seed0))
 total = 0
 for name in ("sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "room23"):
     scene, cam, cfg = scenes.SCENES[name]()
     W, H, B = cfg["width"], cfg["height"], cfg["max_bounces"]
-    p = make_params(W, H, B, spp, seed=0xABCDE + len(name), tile=(32, 8), part=(3 % parts, parts))
+    p = make_params(W, H, B, spp, seed=seed0 + len(name), tile=(32, 8), part=(part, parts))
     t0 = time.time()
     ref = O.OracleScene(scene, L).render(cam, p, threads=0)
     t1 = time.time()
