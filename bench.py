@@ -147,10 +147,27 @@ def main():
     # stream, then D2H on rank 0), so no torch op sits in the timed path.  Only the gloo stand-in used by the tests
     # (several ranks sharing one GPU, which RCCL refuses) goes through torch.distributed.
     lib_collective = world == 1 or backend == "nccl"
+    collective_note = None
     if lib_collective and world > 1:
-        uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0, device=dev)
-        gpu.comm_init(rank, world, uid[0])
+        ok = 1
+        try:
+            uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, device=dev)
+            gpu.comm_init(rank, world, uid[0])
+        except Exception as e:  # e.g. librccl.so not loadable from the library: say so, and let torch's RCCL do the reduce
+            ok, collective_note = 0, "%s: %s" % (type(e).__name__, e)
+        agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            if ok:
+                gpu.comm_destroy()
+            notes = [None] * world
+            dist.all_gather_object(notes, collective_note)
+            collective_note = next((x for x in notes if x), "rptgpu_comm_init failed on another rank")
+            lib_collective = False
+            if rank == 0:
+                print("bench: library collective unavailable (%s); reducing through torch.distributed" % collective_note,
+                      file=sys.stderr)
     frame = None if lib_collective else torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
     render_part = None if lib_collective else D.gpu_render_part(gpu, camera)
     step_no = [0]
@@ -318,7 +335,7 @@ def main():
                        "precision_mode": args.mode,
                        "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")),
                        "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
-                       "collective": ("ncclReduce(sum, f32 framebuffer) to rank 0 inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else "torch.distributed reduce (gloo stand-in)") if world > 1 else "none",
+                       "collective": ("ncclReduce(sum, f32 framebuffer) to rank 0 inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else ("torch.distributed reduce (the library's communicator could not be set up: %s)" % collective_note if collective_note else "torch.distributed reduce (gloo stand-in)")) if world > 1 else "none",
                        "timed_region": "render + reduce + D2H of the f32 frame to pinned host memory on rank 0",
                        "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1),
                        "scene_create_ms": scene_create_ms,
