@@ -179,3 +179,31 @@ def test_cpp_mirror_loaders_equal_the_python_mirror(tmp_path):
         if os.path.exists(path):
             ref = (load_obj(path) if name.endswith(".obj") else load_stl(path)).triangles
             assert (_cpp_rows(path) == ref).all(), name
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF_EXAMPLES), reason="reference tree not present")
+@pytest.mark.parametrize("name,asset", [("teapot", "teapot.obj"), ("cylinder", "cylinder.stl"), ("rustacean", "rustacean.obj"),
+                                        ("metal", "teapot.obj"), ("wine_glass", "wine_glass.obj"), ("fractal_teapots", "teapot.obj"),
+                                        ("pegasus", "pegasus.obj")])
+def test_example_scenes_accept_the_reference_assets(name, asset, monkeypatch):
+    """rpt_amd.scenes' transcriptions of the asset-driven examples, fed the reference's OWN files through
+    scenes.load_asset ($RPT_ASSETS; pegasus.obj comes out of pegasus.zip as in examples/pegasus.rs:17-32): the scene
+    passes the product's flattener (scene_create answers NO_DEVICE here, i.e. validation went through) and the oracle
+    renders a small frame of it with finite values.  (GPU vs oracle on these files: scripts/real_assets.py.)"""
+    import rpt_amd
+    from oracle import oracle_ffi as O
+    from rpt_amd import GpuScene, _abi, make_params, scenes
+    monkeypatch.setenv("RPT_ASSETS", REF_EXAMPLES)
+    mesh = scenes.load_asset(asset)
+    assert mesh is not None and len(mesh.triangles) > 300
+    kw = dict(hdri_size=(64, 32)) if name in ("metal", "wine_glass", "pegasus") else {}
+    scene, cam, cfg = scenes.SCENES[name](mesh=mesh, **kw)
+    try:
+        GpuScene(scene, 0).close()
+    except rpt_amd.RptGpuError as e:
+        assert e.code == _abi.RPTGPU_E_NO_DEVICE, e
+    p = make_params(24, 24, min(cfg["max_bounces"], 3), 2, seed=5, exposure_value=cfg.get("exposure_value", 0.0))
+    img = O.OracleScene(scene).render(cam, p, threads=0)
+    assert img.shape == (24 * 24, 3) and np.isfinite(img).all() and img.max() > 0.0
+    monkeypatch.delenv("RPT_ASSETS")
+    assert scenes.load_asset(asset) is None   # without $RPT_ASSETS the scenes use their stand-ins
