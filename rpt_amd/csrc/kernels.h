@@ -59,8 +59,7 @@ struct KernelTable {
   // object by object with per-tree ray compaction and persistent traversal
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                 int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
-                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook,
-                int mesh_pairs /* meshes: wave-cooperative leaves (rpt_mesh_trace) instead of per-lane leaf loops */);
+                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook);
   size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);
