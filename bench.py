@@ -100,7 +100,6 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
-    ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=None, help="spp of the CPU-baseline sample (default: ~15 s of CPU work)")
@@ -134,7 +133,7 @@ def main():
     H = args.height or cfg["height"]
     B = args.bounces if args.bounces is not None else cfg["max_bounces"]
     spp = args.spp or cfg["num_samples"]
-    precision = _abi.RPT_PRECISION_F64_STRICT if args.mode == "strict" else _abi.RPT_PRECISION_F64_FAST
+    precision = _abi.RPT_PRECISION_F64_STRICT
 
     pipe_flag = {"auto": 0, "persistent": _abi.RPT_FLAG_PERSISTENT, "wavefront": _abi.RPT_FLAG_WAVEFRONT}[args.pipeline]
     torch.cuda.synchronize()
@@ -332,7 +331,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d bounces, %d spp per step (BASELINE configs[1]: examples/cornell.rs)"
                                    % (args.scene, W, H, B, spp) if args.scene == "cornell" else
                                    "%s %dx%d, %d bounces, %d spp per step" % (args.scene, W, H, B, spp),
-                       "precision_mode": args.mode,
+                       "precision_mode": "strict",
                        "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")),
                        "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
                        "collective": ("ncclReduce(sum, f32 framebuffer) to rank 0 inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else ("torch.distributed reduce (the library's communicator could not be set up: %s)" % collective_note if collective_note else "torch.distributed reduce (gloo stand-in)")) if world > 1 else "none",

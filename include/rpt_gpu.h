@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPTGPU_ABI_VERSION 3
+#define RPTGPU_ABI_VERSION 4
 
 /* ---- error codes (replace the reference's panics: buffer.rs:26,33,89, plane.rs:35) ---- */
 enum {
@@ -154,11 +154,12 @@ typedef struct RptCamera {
   double focal_distance;
 } RptCamera;
 
-/* Arithmetic modes.  STRICT is the parity mode: IEEE f64, no FMA contraction, true
- * divisions — the arithmetic of the reference (Rust never contracts).  */
+/* Arithmetic modes.  STRICT is the parity mode and the only one: IEEE f64, no FMA contraction, true
+ * divisions — the arithmetic of the reference (Rust never contracts).  ABI versions <= 3 also had
+ * F64_FAST = 1 (the same kernels with contraction allowed): it measured SLOWER than STRICT and was not
+ * bit-exact, so it was removed; the value 1 is now refused with RPTGPU_E_INVALID_ARGUMENT.  */
 enum {
-  RPT_PRECISION_F64_STRICT = 0,
-  RPT_PRECISION_F64_FAST = 1 /* f64 with FMA contraction allowed (statistically compared) */
+  RPT_PRECISION_F64_STRICT = 0
 };
 
 enum {

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPTGPU_LIB") or os.path.join(HERE, "lib", "librptgpu.so")  # RPTGPU_LIB: dev A/B builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 RPTGPU_OK = 0
 RPTGPU_E_INVALID_ARGUMENT = -1
@@ -27,7 +27,7 @@ RPTGPU_UNIQUE_ID_BYTES = 128
 RPT_SHAPE_SPHERE, RPT_SHAPE_PLANE, RPT_SHAPE_CUBE, RPT_SHAPE_MESH, RPT_SHAPE_GROUP, RPT_SHAPE_MONOMIAL = range(6)
 RPT_LIGHT_POINT, RPT_LIGHT_AMBIENT, RPT_LIGHT_DIRECTIONAL, RPT_LIGHT_OBJECT = range(4)
 RPT_ENV_COLOR, RPT_ENV_HDRI = range(2)
-RPT_PRECISION_F64_STRICT, RPT_PRECISION_F64_FAST = range(2)
+RPT_PRECISION_F64_STRICT = 0  # the only arithmetic mode (ABI v4 removed F64_FAST)
 RPT_FLAG_PROFILE_KERNELS = 1
 RPT_FLAG_WAVEFRONT = 2
 RPT_FLAG_GENERAL_TRAVERSAL = 4

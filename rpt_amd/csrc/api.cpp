@@ -70,29 +70,41 @@ struct Rccl {
   int (*GetUniqueId)(RcclUniqueId*) = nullptr;
   int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
   int (*CommDestroy)(RcclComm) = nullptr;
+  int (*CommAbort)(RcclComm) = nullptr;
   int (*Reduce)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, int, RcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
   std::string why;
 };
 constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0; // ncclFloat32, ncclSum (rccl.h)
-Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+Rccl load_rccl() {
+  Rccl r;
+  // RPTGPU_FAIL_COMM=1: test hook — behave as if librccl.so could not be opened, so that the error paths of
+  // rptgpu_comm_unique_id / rptgpu_comm_init (and bench.py's fallback) can be exercised on any box
+  if (const char* e = std::getenv("RPTGPU_FAIL_COMM"); e && std::atoi(e) != 0) {
+    r.why = "RPTGPU_FAIL_COMM is set (test hook): RCCL treated as unavailable";
+    return r;
+  }
+  std::string err;
   for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
     r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (r.so) break;
+    const char* e = dlerror(); // ONE call: dlerror() clears the message it returns
+    if (e && err.empty()) err = e;
   }
-  if (!r.so) { r.why = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return r; }
+  if (!r.so) { r.why = "dlopen(librccl.so): " + (err.empty() ? std::string("not found") : err); return r; }
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.so, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.so, "ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
+  r.CommAbort = (decltype(r.CommAbort))dlsym(r.so, "ncclCommAbort"); // optional: the failure path of the reduce
   r.Reduce = (decltype(r.Reduce))dlsym(r.so, "ncclReduce");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Reduce;
   if (!r.ok) r.why = "librccl.so lacks an expected symbol";
+  return r;
+}
+Rccl& rccl() {
+  static Rccl r = load_rccl(); // function-local static: initialised once, thread-safe (C++11)
   return r;
 }
 
@@ -193,10 +205,10 @@ int hip_fail(rptgpu_scene* h, const HipError& e) {
 
 // ext: the scene contains a shape of the extended set (RPT_SHAPE_MONOMIAL), which only the *_ext builds
 // of the kernels know; everything else runs the base builds
-const KernelTable* table_for(uint32_t mode, bool ext = false) {
-  if (ext) return mode == RPT_PRECISION_F64_FAST ? &rpt_fast_ext::TABLE : &rpt_strict_ext::TABLE;
-  return mode == RPT_PRECISION_F64_FAST ? &rpt_fast::TABLE : &rpt_strict::TABLE;
+const KernelTable* table_for(uint32_t /*mode: RPT_PRECISION_F64_STRICT is the only one*/, bool ext = false) {
+  return ext ? &rpt_strict_ext::TABLE : &rpt_strict::TABLE;
 }
+const char* const BAD_MODE = "unknown precision_mode (RPT_PRECISION_F64_STRICT = 0 is the only mode; F64_FAST was removed in ABI v4)";
 
 // profiling: bracket a launch with two events from a pool; resolved at the end of the call
 struct Bracket {
@@ -322,6 +334,13 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   h->ws_bounces = max_bounces;
 }
 
+void release_workspace(rptgpu_scene* h) {
+  h->ray.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->nrec.release(); h->rec.release();
+  h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release();
+  h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release();
+  h->ws_cap = 0; h->ws_bounces = 0;
+}
+
 rptdev::Camera make_camera(const RptCamera& c) {
   // Camera::cast_ray derives d and right on every call (camera.rs:66-67); they are constants
   // of the batch, so they are computed once here with the same expressions.
@@ -349,7 +368,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
   if ((uint64_t)p->width * p->height >= (1ull << 31)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "frame too large");
   if (p->part_count && p->part_index >= p->part_count)
     return fail(h, RPTGPU_E_INVALID_ARGUMENT, "part_index >= part_count");
-  if (p->precision_mode > RPT_PRECISION_F64_FAST) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "unknown precision_mode");
+  if (p->precision_mode != RPT_PRECISION_F64_STRICT) return fail(h, RPTGPU_E_INVALID_ARGUMENT, BAD_MODE);
   auto t0 = std::chrono::steady_clock::now();
   try {
     HIP_TRY(hipSetDevice(h->device));
@@ -457,10 +476,22 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           uint64_t have = h->ws_cap * per_path; // what this handle already holds counts as available
           budget = std::min<uint64_t>(budget, (free_b + have) / 2);
         }
-        target = std::min<uint64_t>(128ull << 20, std::max<uint64_t>(4ull << 20, budget / per_path));
+        target = std::min<uint64_t>(128ull << 20, std::max<uint64_t>(1ull << 20, budget / per_path));
       }
       uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, target / npix));
-      ensure_workspace(h, (uint64_t)npix * s_chunk, p->max_bounces);
+      // several handles (or processes) on one GPU each see the same `free` figure: if the pass does not fit after
+      // all, halve it instead of failing the render (a smaller pass is only slower)
+      for (;;) {
+        try {
+          ensure_workspace(h, (uint64_t)npix * s_chunk, p->max_bounces);
+          break;
+        } catch (const HipError& e) {
+          if (e.e != hipErrorOutOfMemory || s_chunk == 1) throw;
+          (void)hipGetLastError(); // clear the sticky error before retrying
+          release_workspace(h);
+          s_chunk = std::max(1u, s_chunk / 2);
+        }
+      }
       h->accum.alloc((uint64_t)npix * 3);
       HIP_TRY(hipMemsetAsync(h->accum.p, 0, (uint64_t)npix * 3 * sizeof(double), st));
 
@@ -822,20 +853,40 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
   } catch (const HipError& e) {
     return hip_fail(h, e);
   }
+  // A rank that cannot take part in the collective must not leave the others waiting in it for ever: the
+  // communicator is aborted (ncclCommAbort makes the peers' pending operations fail) and dropped from the handle.
+  // After any failure here the communicator is gone on this rank; the caller tears the job down or re-initialises.
+  auto abort_comm = [&] {
+    if (world > 1 && h->comm) {
+      Rccl& r = rccl();
+      if (r.CommAbort) (void)r.CommAbort(h->comm);
+      h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+    }
+  };
   // the render leaves this rank's frame (zeros outside its tiles) in frame32; nothing is copied to the host yet
   int rc = render_impl(h, camera, &p, h->frame32.p, true, nullptr, nullptr);
-  if (rc != RPTGPU_OK) return rc;
+  if (rc != RPTGPU_OK) {
+    std::string detail = h->error; // keep the render's own message
+    abort_comm();
+    h->error = detail;
+    return rc;
+  }
   try {
     float* result = h->frame32.p;
     if (world > 1) {
       Rccl& r = rccl();
       int nrc = r.Reduce(h->frame32.p, rank == root ? h->frame32_sum.p : nullptr, (size_t)n, RCCL_FLOAT32, RCCL_SUM, root, h->comm, h->stream);
-      if (nrc != 0) return fail(h, RPTGPU_E_COMM, std::string("ncclReduce: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "error"));
+      if (nrc != 0) {
+        (void)hipStreamSynchronize(h->stream);
+        abort_comm();
+        return fail(h, RPTGPU_E_COMM, std::string("ncclReduce: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "error"));
+      }
       result = h->frame32_sum.p;
     }
     if (rank == root) HIP_TRY(hipMemcpyAsync(out_rgb32, result, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
   } catch (const HipError& e) {
+    abort_comm();
     return hip_fail(h, e);
   }
   return RPTGPU_OK;
@@ -845,7 +896,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
                        uint32_t precision_mode, double* out_t, double* out_normal, int32_t* out_object) {
   if (!h || (n && (!origins || !dirs || !out_t || !out_normal || !out_object)))
     return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
-  if (precision_mode > RPT_PRECISION_F64_FAST) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "unknown precision_mode");
+  if (precision_mode != RPT_PRECISION_F64_STRICT) return fail(h, RPTGPU_E_INVALID_ARGUMENT, BAD_MODE);
   if (!n) return RPTGPU_OK;
   try {
     HIP_TRY(hipSetDevice(h->device));

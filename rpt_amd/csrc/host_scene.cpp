@@ -17,6 +17,9 @@
 #include <map>
 #include <thread>
 #include <cstdlib>
+#include <cstdio>
+#include <system_error>
+#include <sched.h>
 
 namespace rpthost {
 
@@ -186,9 +189,20 @@ void build_forked(const std::vector<Box>& boxes, std::vector<uint32_t>& idx, uin
   Box cl = cell, cr = cell;
   cl.hi[pb.dir] = pb.value; cr.lo[pb.dir] = pb.value;
   KdBuild lb, rb;
-  auto fut = std::async(std::launch::async, [&] { build_subtree(boxes, pb.left, depth + 1, cl, lb, threads / 2); });
-  build_subtree(boxes, pb.right, depth + 1, cr, rb, threads - threads / 2);
-  fut.get();
+  std::future<void> fut;
+  bool forked = false;
+  try { // thread creation can fail under container pid / thread limits: build both children here then (same tree)
+    fut = std::async(std::launch::async, [&] { build_subtree(boxes, pb.left, depth + 1, cl, lb, threads / 2); });
+    forked = true;
+  } catch (const std::system_error&) {
+  }
+  if (forked) {
+    build_subtree(boxes, pb.right, depth + 1, cr, rb, threads - threads / 2);
+    fut.get();
+  } else {
+    build_subtree(boxes, pb.left, depth + 1, cl, lb, 1);
+    build_subtree(boxes, pb.right, depth + 1, cr, rb, 1);
+  }
   splice(out, 1, lb);
   splice(out, 2, rb);
 }
@@ -206,6 +220,23 @@ void build_subtree(const std::vector<Box>& boxes, std::vector<uint32_t>& idx, ui
 
 } // namespace
 
+// CPUs this process may actually run on: the affinity mask and the cgroup v2 quota, not the machine's core count
+// (a GPU box reports 256 logical CPUs and grants 16)
+static int usable_cpus() {
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    double period = 0.0;
+    if (std::fscanf(f, "%31s %lf", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0.0)
+      n = std::min(n, std::max(1, (int)(std::atof(quota) / period)));
+    std::fclose(f);
+  }
+  return n;
+}
+
 void kd_build(const std::vector<Box>& boxes, KdBuild& out, int threads) {
   std::vector<uint32_t> idx(boxes.size());
   Box root;
@@ -218,7 +249,7 @@ void kd_build(const std::vector<Box>& boxes, KdBuild& out, int threads) {
     }
   }
   if (threads <= 0) {
-    threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    threads = usable_cpus();
     if (const char* e = std::getenv("RPTGPU_BUILD_THREADS")) threads = std::max(1, std::atoi(e));
     threads = std::min(threads, 32);
   }

@@ -74,7 +74,5 @@ struct KernelTable {
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)
-namespace rpt_fast { extern const KernelTable TABLE; }   // -ffp-contract=fast
-// the same with the extended shape set (RPT_SHAPE_MONOMIAL) compiled in
+// the same with the extended shape set (RPT_SHAPE_MONOMIAL, trees of trees) compiled in
 namespace rpt_strict_ext { extern const KernelTable TABLE; }
-namespace rpt_fast_ext { extern const KernelTable TABLE; }

@@ -21,7 +21,7 @@ use std::sync::Arc;
 pub mod ffi {
     use std::os::raw::{c_char, c_int, c_void};
 
-    pub const RPTGPU_ABI_VERSION: c_int = 3;
+    pub const RPTGPU_ABI_VERSION: c_int = 4;
     pub const RPTGPU_OK: c_int = 0;
     pub const RPTGPU_E_INVALID_ARGUMENT: c_int = -1;
     pub const RPTGPU_E_UNSUPPORTED_SHAPE: c_int = -2;
@@ -45,7 +45,6 @@ pub mod ffi {
     pub const RPT_ENV_COLOR: i32 = 0;
     pub const RPT_ENV_HDRI: i32 = 1;
     pub const RPT_PRECISION_F64_STRICT: u32 = 0;
-    pub const RPT_PRECISION_F64_FAST: u32 = 1;
     pub const RPT_FLAG_PROFILE_KERNELS: u32 = 1;
     pub const RPT_FLAG_WAVEFRONT: u32 = 2;
     pub const RPT_FLAG_GENERAL_TRAVERSAL: u32 = 4;

@@ -11,5 +11,5 @@ COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off $FLAGS -c kernels_strict.hip -o $B/kernels_strict.o &
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off $FLAGS -x hip -c api.cpp -o $B/api.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/librptgpu_$NAME.so $B/kernels_strict.o $B/api.o build/kernels_fast.o build/kernels_strict_ext.o build/kernels_fast_ext.o build/host_scene.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/librptgpu_$NAME.so $B/kernels_strict.o $B/api.o build/kernels_strict_ext.o build/host_scene.o
 echo built ../lib/librptgpu_$NAME.so
