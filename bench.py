@@ -9,10 +9,20 @@ through the last bounce, the reduce over ranks, and the write of the W*H mean co
 `wall_clock_per_frame_ms`.  With N GPUs rank r renders the tiles tile_id % N == r of the SAME frame
 (strong scaling) and the f32 framebuffers are summed to rank 0 by one RCCL reduce per step.
 
-    python bench.py                      # 1 GPU
+    python bench.py                      # 1 GPU: the headline (C2) + the other BASELINE configs + live counters
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-    python bench.py --scene dragon --spp 16          # another BASELINE config at ITS frame size
+    python bench.py --scene dragon --spp 16          # another BASELINE config at ITS frame size, nothing else
+    python bench.py --scene simple_video             # scene rebuilt per frame (examples/simple_video.rs): frames/s
+
+The default 1-GPU run prints ONE JSON line.  Besides the headline it carries
+  * `other_configs`: BASELINE configs[2-4] (dragon-class mesh, fractal spheres, wine glass) at their own frame
+    sizes and a reduced spp (cost per sample does not depend on spp), 2 steps + 1 warm-up each, each with its
+    own roofline object and CPU baseline;
+  * `roofline` objects whose counter fields (VALU busy, lanes active per VALU instruction, HBM bytes, L2 requests)
+    are measured IN THIS RUN: bench.py re-runs one step of each workload under `rocprofv3 --pmc ... --kernel-trace`
+    in a child process (no torch, ~10 s per pass) and reads the counters back.  If rocprofv3 is not usable the
+    fields fall back to the newest committed profiles/r*_<scene>_pmc.json and `pmc_source` says so.
 """
 import argparse
 import json
@@ -23,15 +33,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import rpt_amd  # noqa: E402
-from rpt_amd import _abi, make_params, scenes  # noqa: E402
-from rpt_amd import distributed as D  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+L2_PEAK_GBS = 34500.0    # ibid.: aggregate L2 bandwidth, 8 XCDs
+# f64 VALU lane slots per second: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz, halved because an f64 instruction
+# occupies the SIMD-32 for twice the cycles of an f32 one (78.6 TFLOP/s f64 FMA = 2 flops x this number)
+VALU_F64_PEAK_TLANES = 256 * 4 * 32 * 2.4e9 / 2 / 1e12
+NUM_SIMD, NUM_SE = 1024, 32
 
 # SURVEY §8d accounting constants, f64 layout (every float field of the f32 layout doubles)
 RAY_IO = 2 * (32 + 16)
@@ -40,6 +47,12 @@ SHADE_GEOM, MATERIAL = 72, 64
 STATE_RW, FOLD_RW = 2 * 192, 2 * 48
 ENV = 4 * 32
 FB = 24
+
+# the other BASELINE configs in the default run: (scene, spp per step).  Frame size and bounces are the config's own.
+OTHER_CONFIGS = (("dragon", 32), ("fractal_spheres", 8), ("wine_glass", 8))
+PMC_A = "FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
+PMC_B = "WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM"
+PMC_C = "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
 
 
 def algorithmic_bytes(c, env_is_hdri):
@@ -90,26 +103,358 @@ def cpu_model():
     return "unknown"
 
 
+def short_kernel(name):
+    """'void rpt_strict::rpt_paths<rpt_strict::KdFlat>(rptdev::Scene, ...)' -> 'rpt_paths'"""
+    import re
+    head = name.split("(")[0]
+    head = re.sub(r"\b\w+::", "", head).replace("void ", "").strip()
+    for k in ("rpt_paths", "rpt_tree_trace", "rpt_tree_enter", "rpt_rays_init", "rpt_rays_objects", "rpt_finish",
+              "rpt_tree_general", "rpt_shadow_rays"):
+        if head.startswith(k + "<"):
+            return k
+    return head
+
+
+# ---------------------------------------------------------------------------------------------- live counters
+def pmc_worker(args):
+    """Child of live_pmc(): ONE step of the workload through the same C-ABI call the bench times, nothing else
+    (no torch: the process is up in a second).  Runs under rocprofv3."""
+    import numpy as np
+    import rpt_amd
+    from rpt_amd import _abi, make_params, scenes
+    scene, camera, cfg = scenes.SCENES[args.scene]()
+    W, H = args.width or cfg["width"], args.height or cfg["height"]
+    B = args.bounces if args.bounces is not None else cfg["max_bounces"]
+    spp = args.spp or cfg["num_samples"]
+    flag = {"auto": 0, "persistent": _abi.RPT_FLAG_PERSISTENT, "wavefront": _abi.RPT_FLAG_WAVEFRONT}[args.pipeline]
+    gpu = rpt_amd.GpuScene(scene, 0)
+    out = np.empty(W * H * 3, dtype=np.float32)
+    gpu.render_batch_reduce(camera, make_params(W, H, B, spp, seed=0x52505447, flags=flag), root=0, out=out)
+    gpu.close()
+
+
+def derive_counters(d, samples, total_us):
+    """per-kernel derived metrics from summed raw counters `d` (name -> value) of the launches of one kernel"""
+    g = d.get
+    t = {}
+    if g("FETCH_SIZE") is not None:
+        t["fetch_bytes_x2"] = 2 * g("FETCH_SIZE") * 1024  # gfx950 tallies 128-B requests at 64 B (MI355X_MICROARCH.md)
+    if g("WRITE_SIZE") is not None:
+        t["write_bytes"] = g("WRITE_SIZE") * 1024
+    if "fetch_bytes_x2" in t:
+        t["hbm_bytes"] = t["fetch_bytes_x2"] + t.get("write_bytes", 0.0)
+        t["hbm_bytes_is"] = "2 x FETCH_SIZE + WRITE_SIZE" if "write_bytes" in t else "2 x FETCH_SIZE (no WRITE_SIZE pass)"
+        if samples:
+            t["hbm_bytes_per_sample"] = t["hbm_bytes"] / samples
+        if total_us:
+            t["hbm_GBs"] = t["hbm_bytes"] / 1e9 / (total_us / 1e6)
+            t["hbm_frac"] = t["hbm_GBs"] / HBM_PEAK_GBS
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
+        t["l2_hit_rate"] = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+        req = g("TCC_HIT_sum") + g("TCC_MISS_sum")
+        if total_us:  # one TCC request moves at most one 128-B line: an upper bound of the bytes the L2s served
+            t["l2_GBs_upper"] = req * 128.0 / 1e9 / (total_us / 1e6)
+            t["l2_frac_upper"] = t["l2_GBs_upper"] / L2_PEAK_GBS
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_BUSY_CYCLES"):
+        t["valu_busy"] = g("SQ_ACTIVE_INST_VALU") * 4 / (NUM_SIMD * g("SQ_BUSY_CYCLES") / NUM_SE)
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+        t["lanes_active"] = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
+    if "valu_busy" in t and "lanes_active" in t:
+        t["valu_frac"] = t["valu_busy"] * t["lanes_active"] / 64.0
+    if g("SQ_WAIT_ANY") is not None and g("SQ_WAVE_CYCLES"):
+        t["wait_frac"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+    if g("SQ_INST_LEVEL_VMEM") and (g("SQ_INSTS_VMEM_RD") or 0) + (g("SQ_INSTS_VMEM_WR") or 0) > 0:
+        t["vmem_latency_cycles"] = g("SQ_INST_LEVEL_VMEM") / ((g("SQ_INSTS_VMEM_RD") or 0) + (g("SQ_INSTS_VMEM_WR") or 0))
+    return t
+
+
+def live_pmc(scene, spp, passes, extra=(), timeout=150):
+    """One step of `scene` at `spp` under `rocprofv3 --pmc <pass> --kernel-trace`, once per counter pass (FETCH_SIZE
+    and WRITE_SIZE do not fit one pass; never combined with sys / hip / hsa tracing).  Returns ({kernel: derived},
+    note) — the counters of THIS run on THIS box — or (None, why)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    raw, dur, note = {}, {}, None
+    tmp = tempfile.mkdtemp(prefix="rptpmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, counters in enumerate(passes):
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--pmc"] + counters.split() + ["--kernel-trace", "-d", d, "-o", "w", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-worker", "--scene", scene, "--spp", str(spp)] + list(extra)
+            why = None
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+                dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+                if r.returncode != 0 or not dbs:
+                    why = "rocprofv3 pass %d failed (rc %d): %s" % (i, r.returncode, r.stdout.decode(errors="replace")[-300:])
+            except subprocess.TimeoutExpired:
+                why = "rocprofv3 pass %d timed out" % i
+            if why:  # the SQ pass is the one the roofline needs; a later pass that fails only costs its own fields
+                if i == 0:
+                    return None, why
+                note = why
+                continue
+            try:
+                c = sqlite3.connect(dbs[0])
+                for k, cn, total in c.execute("select kernel_name, counter_name, sum(value) from counters_collection "
+                                              "group by kernel_name, counter_name"):
+                    raw.setdefault(short_kernel(k), {})[cn] = total
+                if i == 0:  # the kernels' durations INSIDE the counter run (microseconds), the denominator of its byte rates
+                    for name, tot in c.execute("select name, total_duration from top_kernels"):
+                        dur[short_kernel(name)] = dur.get(short_kernel(name), 0.0) + tot
+                c.close()
+            except Exception as e:
+                if i == 0:
+                    return None, "reading the rocprofv3 database failed: %s" % e
+                note = "pass %d: %s" % (i, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"raw": raw, "dur_us": dur, "note": note}, None
+
+
+# ---------------------------------------------------------------------------------------------- one workload
+class Workload:
+    """one BASELINE config on this rank: scene on the device, step(), timing, accounting"""
+
+    def __init__(self, name, args, rank, world, local_rank, backend, spp=None, is_headline=True):
+        import rpt_amd
+        from rpt_amd import _abi, scenes
+        self.name, self.args, self.rank, self.world = name, args, rank, world
+        self.scene, self.camera, cfg = scenes.SCENES[name]()
+        self.W = (args.width if is_headline else None) or cfg["width"]
+        self.H = (args.height if is_headline else None) or cfg["height"]
+        self.B = args.bounces if (is_headline and args.bounces is not None) else cfg["max_bounces"]
+        self.spp = spp or (args.spp if is_headline else None) or cfg["num_samples"]
+        self.pipe_flag = {"auto": 0, "persistent": _abi.RPT_FLAG_PERSISTENT, "wavefront": _abi.RPT_FLAG_WAVEFRONT}[args.pipeline]
+        t0 = time.perf_counter()
+        self.gpu = rpt_amd.GpuScene(self.scene, local_rank)  # flatten + kd build (reference rule) + upload
+        self.scene_create_ms = (time.perf_counter() - t0) * 1e3
+        self.step_no = 0
+
+    def params(self, **kw):
+        from rpt_amd import _abi, make_params
+        base = 0 if self.args.fixed_samples else self.step_no * self.spp
+        return make_params(self.W, self.H, self.B, self.spp, seed=0x52505447, sample_index_base=base,
+                           flags=_abi.RPT_FLAG_PROFILE_KERNELS | self.pipe_flag, **kw)
+
+    def close(self):
+        self.gpu.close()
+
+
+def accounting(wl, st):
+    """§8d algorithmic bytes per kernel kind for what this rank traced (st.samples): visit counts of the REFERENCE
+    algorithm from the instrumented oracle on a bounded sample (1 spp on 1/8 of the tiles), scaled linearly"""
+    from oracle import oracle_ffi as O
+    from rpt_amd import make_params
+    osc = O.OracleScene(wl.scene)
+    pc = make_params(wl.W, wl.H, wl.B, 1, seed=0x52505447, tile=(32, 8), part=(0, 8))
+    _, cnt = osc.render(wl.camera, pc, threads=0, counters=True)
+    scale = float(st.samples) / max(1, cnt["samples"])
+    bytes_k = {k: v * scale for k, v in algorithmic_bytes(cnt, wl.scene.environment.hdri is not None).items()}
+    bytes_k["rpt_tree_enter+sort"] = 0.0
+    return bytes_k, osc
+
+
+def cpu_baseline(wl, osc, budget_s, cpu_spp=None):
+    """the oracle (uninstrumented -march=native build) on this box's host cores, on a sample sized for ~budget_s"""
+    from oracle import oracle_ffi as O
+    from rpt_amd import make_params
+    ncores, raw = host_cpus()
+    L, how = O.baseline_lib(native=True)
+    fast = O.OracleScene(wl.scene, L)
+    W, H, B = wl.W, wl.H, wl.B
+    pcal = make_params(W, H, B, 1, seed=0x52505447, tile=(32, 8), part=(0, 8))  # calibrate on 1 spp of 1/8 of the frame
+    t1 = time.perf_counter()
+    fast.render(wl.camera, pcal, threads=ncores)
+    rate = (W * H / 8.0) / max(1e-6, time.perf_counter() - t1)
+    want = rate * budget_s / (W * H)
+    part = (0, 1)
+    if want < 1.0:  # not even one spp of the whole frame fits: take 1 spp on a fraction of the tiles
+        part = (0, int(min(64, max(2, round(1.0 / max(want, 1e-3))))))
+    spp = cpu_spp or int(min(64, max(1, round(want))))
+    pcpu = make_params(W, H, B, spp, seed=0x52505447, tile=(32, 8), part=part)
+    t1 = time.perf_counter()
+    fast.render(wl.camera, pcpu, threads=ncores)
+    dt = time.perf_counter() - t1
+    n_samples = W * H * spp / part[1]
+    cpu = {"value": n_samples / dt / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
+           "sample": "%s %dx%d, %d bounces, %d spp%s (%.1f s wall): C++ restatement of rpt's rayon path (oracle/, %s), one task "
+                     "per row claimed dynamically by %d std::threads on %s (%d logical CPUs)"
+                     % (wl.name, W, H, B, spp, "" if part[1] == 1 else " on 1/%d of the 32x8 tiles" % part[1], dt, how, ncores,
+                        cpu_model(), raw)}
+    if osc is not None and budget_s >= 8:  # the instrumented checker build on a quarter of that sample, for the record
+        pins = make_params(W, H, B, max(1, spp // 4), seed=0x52505447, tile=(32, 8), part=part)
+        t1 = time.perf_counter()
+        osc.render(wl.camera, pins, threads=ncores)
+        dti = time.perf_counter() - t1
+        cpu["instrumented_checker_build"] = {"value": W * H * pins.iterations / part[1] / dti / 1e6, "unit": "Msamples/s",
+                                             "note": "liboracle.so with visit counters compiled in (x86-64-v3)"}
+    return cpu
+
+
+def kernel_table(wl, st, bytes_k):
+    from rpt_amd import _abi
+    NK = _abi.RPT_K_COUNT
+    names = [wl.gpu.lib.rptgpu_kernel_name(k).decode() for k in range(NK)]
+    kern_ms = {names[k]: st.kernel_ms[k] for k in range(NK)}
+    kern_n = {names[k]: int(st.kernel_launches[k]) for k in range(NK)}
+    names = [k for k in names if kern_n[k] > 0]
+    # the kernel the roofline line is about: the one with the most time among the disjoint kinds, or the
+    # per-tree traversal when it is the bulk of the queries that contain it (scenes with deep trees)
+    disjoint = {k: kern_ms[k] for k in names if k not in ("rpt_tree_trace", "rpt_tree_enter+sort")}
+    dominant = max(disjoint, key=disjoint.get)
+    if "rpt_tree_trace" in names and kern_ms["rpt_tree_trace"] >= 0.5 * (kern_ms.get("rpt_extend", 0) + kern_ms.get("rpt_shadow", 0)) \
+            and dominant in ("rpt_extend", "rpt_shadow"):
+        dominant = "rpt_tree_trace"
+    kernels = {}
+    for k in names:
+        ms, n = kern_ms[k], max(1, kern_n[k])
+        kernels[k] = {"launches": kern_n[k], "avg_ms": ms / n, "total_ms": ms,
+                      "alg_GB_per_launch": bytes_k.get(k, 0.0) / n / 1e9,
+                      "accounting_GBs": (bytes_k.get(k, 0.0) / 1e9) / (ms / 1e3) if ms > 0 else None}
+    return kernels, dominant, kern_n
+
+
+def roofline_object(wl, st, kernels, dominant, kern_n, bytes_k, pmc, pmc_note, pmc_spp):
+    """What bounds the dominant kernel.  This path is branchy scalar f64 whose scenes live in LDS / L2: the roof is the
+    f64 VALU — useful lane slots per second — not HBM.  `frac` = VALU busy x lanes active / 64 from the SQ counters;
+    `accounting_frac` is SURVEY §8d's figure (algorithmic bytes of the REFERENCE traversal / time / 8 TB/s), kept for the
+    contract: it exceeds 1 wherever this traversal skips work the reference's does (leaf-box filter), so it is an
+    accounting number, not a fraction of any roof."""
+    rank_samples = float(st.samples)
+    acc = kernels[dominant]["accounting_GBs"]
+    roof = {"bound": "valu", "kernel": dominant, "unit": "Tlane-slot/s (f64 VALU: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2)",
+            "peak": VALU_F64_PEAK_TLANES, "achieved": None, "frac": None, "traffic": None,
+            "accounting_GBs": acc, "accounting_frac": (acc / HBM_PEAK_GBS) if acc else None,
+            "accounting_is": "SURVEY §8d algorithmic bytes of the REFERENCE traversal / launch time / 8 TB/s (may exceed 1)",
+            "alg_bytes_per_sample": bytes_k["rpt_paths"] / rank_samples if rank_samples else None,
+            "kernels": kernels}
+    k, src = None, None
+    if pmc is not None:
+        raw = pmc["raw"].get(dominant)
+        if raw:
+            W, H = wl.W, wl.H
+            k = derive_counters(raw, float(W) * H * pmc_spp, pmc["dur_us"].get(dominant))
+            src = "live: rocprofv3 --pmc passes of one %d-spp step of this workload, run by this bench.py invocation" % pmc_spp
+    if k is None:  # fall back to the committed summary of an earlier profile of the same workload
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % wl.name)))
+        path = wl.args.pmc_json or (cands[-1] if cands else None)
+        if path and os.path.exists(path):
+            try:
+                pj = json.load(open(path))
+                k = dict(pj.get("kernels", {}).get(dominant) or {})
+                if "hbm_frac_in_pmc_run" in k:
+                    k["hbm_frac"], k["hbm_GBs"] = k["hbm_frac_in_pmc_run"], k.get("hbm_GBs_in_pmc_run")
+                src = "COMMITTED, not measured in this run: %s (%s)%s" % (os.path.relpath(path, ROOT), pj.get("workload", ""),
+                                                                           "; live attempt: " + pmc_note if pmc_note else "")
+            except Exception as e:
+                roof["pmc_error"] = str(e)
+    if k:
+        roof["pmc_source"] = src
+        for f in ("valu_busy", "lanes_active", "valu_frac", "wait_frac", "l2_hit_rate", "l2_GBs_upper", "l2_frac_upper",
+                  "vmem_latency_cycles", "hbm_frac", "hbm_bytes_is"):
+            if k.get(f) is not None:
+                roof[f] = k[f]
+        if k.get("hbm_GBs") is not None:
+            roof["hbm_measured_GBs"] = k["hbm_GBs"]
+        if k.get("hbm_bytes_per_sample") is not None:  # per launch of the dominant kernel in the timed run, like `achieved`
+            roof["traffic"] = k["hbm_bytes_per_sample"] * rank_samples / max(1, kern_n[dominant])
+        if k.get("valu_frac") is not None:
+            roof["frac"] = min(1.0, k["valu_frac"])
+            roof["achieved"] = roof["frac"] * VALU_F64_PEAK_TLANES
+        hf, vf, wf = k.get("hbm_frac") or 0.0, k.get("valu_busy") or 0.0, k.get("wait_frac") or 0.0
+        roof["bound"] = "hbm" if hf >= max(vf, 0.5) else ("valu" if vf >= 0.6 or vf > wf else "latency")
+    elif pmc_note:
+        roof["pmc_source"] = "none: " + pmc_note
+    return roof
+
+
+def run_simple_video(args, local_rank):
+    """examples/simple_video.rs:10-56: the scene is rebuilt for every frame, so what is timed per frame is scene
+    hand-off (flatten + kd build + upload) + render + the frame's arrival in host memory."""
+    import numpy as np
+    import rpt_amd
+    from rpt_amd import _abi, make_params, scenes
+    frames = max(1, args.steps if args.steps != 3 else 30)
+    out, t_create, t_render = None, 0.0, 0.0
+    sc0, cam0, cfg = scenes.simple_video(0)
+    W, H = args.width or cfg["width"], args.height or cfg["height"]
+    B = args.bounces if args.bounces is not None else cfg["max_bounces"]
+    spp = args.spp or cfg["num_samples"]
+    out = np.empty(W * H * 3, dtype=np.float32)
+    for w in range(args.warmup):  # the first handle of a process pays HIP / module initialisation
+        g = rpt_amd.GpuScene(sc0, local_rank)
+        g.render_batch_reduce(cam0, make_params(W, H, B, spp), root=0, out=out)
+        g.close()
+    per_frame = []
+    t_all = time.perf_counter()
+    for f in range(frames):
+        sc, cam, _ = scenes.simple_video(f)
+        t0 = time.perf_counter()
+        g = rpt_amd.GpuScene(sc, local_rank)
+        t1 = time.perf_counter()
+        g.render_batch_reduce(cam, make_params(W, H, B, spp), root=0, out=out)
+        t2 = time.perf_counter()
+        g.close()
+        t_create += t1 - t0
+        t_render += t2 - t1
+        per_frame.append((t1 - t0) * 1e3)
+    total = time.perf_counter() - t_all
+    print(json.dumps({"metric": "frames/s (scene rebuilt per frame)", "value": frames / total, "unit": "frames/s", "n_gpus": 1,
+                      "steps": frames, "warmup": args.warmup, "ms_per_step": total / frames * 1e3, "higher_is_better": True,
+                      "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": "simple_video %dx%d, %d bounces, %d spp, %d frames, a new scene per frame "
+                                             "(examples/simple_video.rs:10-56)" % (W, H, B, spp, frames),
+                                 "scene_create_ms_mean": t_create / frames * 1e3, "scene_create_ms_first": per_frame[0],
+                                 "scene_create_ms_median": sorted(per_frame)[len(per_frame) // 2],
+                                 "render_ms_mean": t_render / frames * 1e3,
+                                 "python_scene_build_ms_mean": (total - t_create - t_render) / frames * 1e3}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per step (default: the config's own)")
-    ap.add_argument("--scene", default="cornell", choices=sorted(scenes.SCENES))
+    ap.add_argument("--scene", default=None, help="one workload only (default: cornell = the headline, plus the other configs)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--pipeline", default="auto", choices=["auto", "persistent", "wavefront"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=None, help="spp of the CPU-baseline sample (default: ~15 s of CPU work)")
+    ap.add_argument("--no-other-configs", action="store_true", help="headline only")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run a step under rocprofv3 for the counter fields")
+    ap.add_argument("--cpu-spp", type=int, default=None, help="spp of the CPU-baseline sample (default: ~12 s of CPU work)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last step's reduced f32 frame (.npy)")
     ap.add_argument("--fixed-samples", action="store_true", help="every step renders the same samples (tests)")
     ap.add_argument("--emulate-part-of", type=int, default=0, metavar="N",
                     help="single process: render only the tiles rank 0 would own among N ranks (no collective) and report "
                          "the step time, i.e. the per-rank cost that bounds N-GPU scaling; the JSON line is NOT a bench result")
-    ap.add_argument("--pmc-json", default=None, help="rocprofv3 PMC summary of this workload (default: profiles/<latest>_<scene>_pmc.json)")
+    ap.add_argument("--pmc-json", default=None, help="committed rocprofv3 PMC summary to fall back to (default: profiles/<latest>_<scene>_pmc.json)")
+    ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    default_run = args.scene is None
+    args.scene = args.scene or "cornell"
+    if args.pmc_worker:
+        return pmc_worker(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rpt_amd
+    from rpt_amd import _abi, make_params, scenes
+    from rpt_amd import distributed as D
+    if args.scene not in scenes.SCENES:
+        ap.error("unknown scene %r (known: %s)" % (args.scene, ", ".join(sorted(scenes.SCENES))))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,19 +472,12 @@ def main():
     assert world == args.gpus or world == 1, "--gpus must match the launcher's world size"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.scene == "simple_video" and world == 1:
+        return run_simple_video(args, local_rank)
 
-    scene, camera, cfg = scenes.SCENES[args.scene]()
-    W = args.width or cfg["width"]
-    H = args.height or cfg["height"]
-    B = args.bounces if args.bounces is not None else cfg["max_bounces"]
-    spp = args.spp or cfg["num_samples"]
-    precision = _abi.RPT_PRECISION_F64_STRICT
-
-    pipe_flag = {"auto": 0, "persistent": _abi.RPT_FLAG_PERSISTENT, "wavefront": _abi.RPT_FLAG_WAVEFRONT}[args.pipeline]
     torch.cuda.synchronize()
-    t_create = time.perf_counter()
-    gpu = rpt_amd.GpuScene(scene, local_rank)  # flatten + kd build (reference rule) + upload
-    scene_create_ms = (time.perf_counter() - t_create) * 1e3
+    wl = Workload(args.scene, args, rank, world, local_rank, backend)
+    W, H, B, spp, gpu, camera = wl.W, wl.H, wl.B, wl.spp, wl.gpu, wl.camera
     host_frame = torch.empty(W * H * 3, dtype=torch.float32).pin_memory()
     host_np = host_frame.numpy()
     # The collective lives in the library (rptgpu_comm_init / rptgpu_render_batch_reduce: ncclReduce on the library's
@@ -148,16 +486,26 @@ def main():
     lib_collective = world == 1 or backend == "nccl"
     collective_note = None
     if lib_collective and world > 1:
+        # Step 1, local and cheap: can THIS rank open RCCL from the library at all?  Agreed on by every rank BEFORE anyone
+        # enters ncclCommInitRank — a rank that cannot would otherwise leave the others blocked in the rendezvous.
         ok = 1
         try:
-            uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0, device=dev)
-            gpu.comm_init(rank, world, uid[0])
-        except Exception as e:  # e.g. librccl.so not loadable from the library: say so, and let torch's RCCL do the reduce
+            rpt_amd.GpuScene.comm_unique_id()
+        except Exception as e:
             ok, collective_note = 0, "%s: %s" % (type(e).__name__, e)
         agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed.item()) == 0:
+        if int(agreed.item()) == 1:
+            # Step 2: the communicator.  ncclCommInitRank either succeeds or fails on every rank (it is itself a rendezvous)
+            try:
+                uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0, device=dev)
+                gpu.comm_init(rank, world, uid[0])
+            except Exception as e:
+                ok, collective_note = 0, "%s: %s" % (type(e).__name__, e)
+            agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:  # say why, and let torch's RCCL do the reduce
             if ok:
                 gpu.comm_destroy()
             notes = [None] * world
@@ -169,11 +517,9 @@ def main():
                       file=sys.stderr)
     frame = None if lib_collective else torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
     render_part = None if lib_collective else D.gpu_render_part(gpu, camera)
-    step_no = [0]
 
     def step():
-        p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=0 if args.fixed_samples else step_no[0] * spp,
-                        precision=precision, flags=_abi.RPT_FLAG_PROFILE_KERNELS | pipe_flag)
+        p = wl.params()
         if lib_collective:
             # Renderer::sample on every rank; ends with the colours in host memory on rank 0 (renderer.rs:127-128)
             gpu.render_batch_reduce(camera, p, root=0, out=host_np)
@@ -181,7 +527,7 @@ def main():
             D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
             if rank == 0:
                 host_frame.copy_(frame, non_blocking=False)
-        step_no[0] += 1
+        wl.step_no += 1
 
     def fence():
         torch.cuda.synchronize()
@@ -190,16 +536,14 @@ def main():
         torch.cuda.synchronize()
 
     if args.emulate_part_of > 1 and world == 1:
-        out32 = host_np
+        import ctypes as C
+        dframe = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
 
         def step():  # noqa: F811 — what one of N ranks does between the collectives
-            p = make_params(W, H, B, spp, seed=0x52505447, sample_index_base=step_no[0] * spp, precision=precision,
-                            flags=_abi.RPT_FLAG_PROFILE_KERNELS | pipe_flag, tile=(32, 8), part=(0, args.emulate_part_of))
+            p = wl.params(tile=(32, 8), part=(0, args.emulate_part_of))
             cam = camera.lower()
-            import ctypes as C
             _abi.check(gpu.lib.rptgpu_render_batch_device(gpu.handle, C.byref(cam), C.byref(p), C.c_void_p(dframe.data_ptr()), 1, None), gpu.handle)
-            step_no[0] += 1
-        dframe = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
+            wl.step_no += 1
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -233,96 +577,19 @@ def main():
     if rank == 0:
         total_samples = float(W) * H * spp * args.steps
         value = total_samples / elapsed / 1e6
-        NK = _abi.RPT_K_COUNT
-        names = [gpu.lib.rptgpu_kernel_name(k).decode() for k in range(NK)]
-        kern_ms = {names[k]: st.kernel_ms[k] for k in range(NK)}
-        kern_n = {names[k]: int(st.kernel_launches[k]) for k in range(NK)}
-        names = [k for k in names if kern_n[k] > 0]
-
-        # visit counts of the reference algorithm for this workload, from the instrumented oracle
-        # on a bounded sample (1 spp on 1/8 of the tiles); they scale linearly with samples
-        from oracle import oracle_ffi as O
-        osc = O.OracleScene(scene)
-        pc = make_params(W, H, B, 1, seed=0x52505447, tile=(32, 8), part=(0, 8))
-        _, cnt = osc.render(camera, pc, threads=0, counters=True)
-        rank_samples = float(st.samples)  # what THIS rank traced in the timed region
-        scale = rank_samples / max(1, cnt["samples"])
-        bytes_k = {k: v * scale for k, v in algorithmic_bytes(cnt, scene.environment.hdri is not None).items()}
-        bytes_k["rpt_tree_enter+sort"] = 0.0
-        # the kernel the roofline line is about: the one with the most time among the disjoint kinds, or the
-        # per-tree traversal when it is the bulk of the queries that contain it (scenes with deep trees)
-        disjoint = {k: kern_ms[k] for k in names if k not in ("rpt_tree_trace", "rpt_tree_enter+sort")}
-        dominant = max(disjoint, key=disjoint.get)
-        if "rpt_tree_trace" in names and kern_ms["rpt_tree_trace"] >= 0.5 * (kern_ms.get("rpt_extend", 0) + kern_ms.get("rpt_shadow", 0)) \
-                and dominant in ("rpt_extend", "rpt_shadow"):
-            dominant = "rpt_tree_trace"
-        kernels = {}
-        for k in names:
-            ms, n = kern_ms[k], max(1, kern_n[k])
-            kernels[k] = {"launches": kern_n[k], "avg_ms": ms / n, "total_ms": ms,
-                          "alg_GB_per_launch": bytes_k[k] / n / 1e9,
-                          "achieved_GBs": (bytes_k[k] / 1e9) / (ms / 1e3) if ms > 0 else None}
-        ach = kernels[dominant]["achieved_GBs"]
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
-                    "alg_bytes_per_sample": bytes_k["rpt_paths"] / rank_samples,
-                    "achieved_is": "SURVEY §8d algorithmic bytes of the REFERENCE traversal / launch time (an accounting "
-                                   "figure); hbm_measured_GBs is what the fabric counters saw",
-                    "kernels": kernels}
-        # measured counters of the same workload (rocprofv3 PMC passes, scripts/profile.sh + summarize_profile.py)
-        pmc_path = args.pmc_json
-        if pmc_path is None:
-            import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % args.scene)))
-            pmc_path = cands[-1] if cands else None
-        if pmc_path and os.path.exists(pmc_path):
-            try:
-                pj = json.load(open(pmc_path))
-                k = pj.get("kernels", {}).get(dominant)
-                if k:
-                    n_l = max(1, kern_n[dominant])
-                    roofline["pmc_source"] = "%s (%s)" % (os.path.relpath(pmc_path, ROOT), pj.get("workload", ""))
-                    if k.get("hbm_bytes_per_sample") is not None:
-                        roofline["traffic"] = k["hbm_bytes_per_sample"] * rank_samples / n_l
-                        roofline["hbm_measured_GBs"] = roofline["traffic"] / 1e9 / (kernels[dominant]["avg_ms"] / 1e3)
-                        roofline["hbm_frac"] = roofline["hbm_measured_GBs"] / HBM_PEAK_GBS
-                    for f in ("valu_busy", "lanes_active", "valu_frac", "wait_frac", "l2_hit_rate", "vmem_latency_cycles"):
-                        if k.get(f) is not None:
-                            roofline[f] = k[f]
-                    # what bounds the kernel, from the data: the larger of the HBM fraction and the useful-lane
-                    # VALU fraction names the roof; a kernel whose waves wait most of their cycles with neither
-                    # near its roof is latency-bound
-                    hf, vf, wf = roofline.get("hbm_frac") or 0.0, k.get("valu_busy") or 0.0, k.get("wait_frac") or 0.0
-                    roofline["bound"] = "hbm" if hf >= max(vf, 0.5) else ("valu" if vf >= 0.6 or vf > wf else "latency")
-            except Exception as e:  # a malformed summary must not cost the bench line
-                roofline["pmc_error"] = str(e)
-
+        bytes_k, osc = accounting(wl, st)
+        kernels, dominant, kern_n = kernel_table(wl, st, bytes_k)
+        live = world == 1 and not args.no_live_pmc
+        pmc, pmc_note = (None, "live counters are collected at N=1 only" if world > 1 else "--no-live-pmc")
+        extra = ["--pipeline", args.pipeline] + (["--width", str(W), "--height", str(H)] if (args.width or args.height) else []) \
+            + (["--bounces", str(B)] if args.bounces is not None else [])
+        if live:
+            gpu.close()  # the child renders the same workload on the same GPU: give the memory back first
+            pmc, pmc_note = live_pmc(args.scene, spp, (PMC_A, PMC_B, PMC_C), extra)
+        roofline = roofline_object(wl, st, kernels, dominant, kern_n, bytes_k, pmc, pmc_note, spp)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            ncores, raw = host_cpus()
-            L, how = O.baseline_lib(native=True)
-            fast = O.OracleScene(scene, L)
-            # calibrate on 1 spp of 1/8 of the frame, then size the sample for ~15 s of wall time
-            pcal = make_params(W, H, B, 1, seed=0x52505447, tile=(32, 8), part=(0, 8))
-            t1 = time.perf_counter()
-            fast.render(camera, pcal, threads=ncores)
-            rate = (W * H / 8.0) / max(1e-6, time.perf_counter() - t1)
-            cpu_spp = args.cpu_spp or int(min(64, max(1, round(rate * 15.0 / (W * H)))))
-            pcpu = make_params(W, H, B, cpu_spp, seed=0x52505447)
-            t1 = time.perf_counter()
-            fast.render(camera, pcpu, threads=ncores)
-            dt = time.perf_counter() - t1
-            # the instrumented checker build on a quarter of that sample, for the record
-            pins = make_params(W, H, B, max(1, cpu_spp // 4), seed=0x52505447)
-            t1 = time.perf_counter()
-            osc.render(camera, pins, threads=ncores)
-            dti = time.perf_counter() - t1
-            cpu = {"value": W * H * cpu_spp / dt / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
-                   "sample": "%s %dx%d, %d bounces, %d spp (%.1f s wall): C++ restatement of rpt's rayon path (oracle/, %s), one task "
-                             "per row claimed dynamically by %d std::threads on %s (%d logical CPUs)"
-                             % (args.scene, W, H, B, cpu_spp, dt, how, ncores, cpu_model(), raw),
-                   "instrumented_checker_build": {"value": W * H * pins.iterations / dti / 1e6, "unit": "Msamples/s",
-                                                  "note": "liboracle.so with visit counters compiled in (x86-64-v3)"}}
+            cpu = cpu_baseline(wl, osc, 12.0, args.cpu_spp)
 
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -337,11 +604,52 @@ def main():
                        "collective": ("ncclReduce(sum, f32 framebuffer) to rank 0 inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else ("torch.distributed reduce (the library's communicator could not be set up: %s)" % collective_note if collective_note else "torch.distributed reduce (gloo stand-in)")) if world > 1 else "none",
                        "timed_region": "render + reduce + D2H of the f32 frame to pinned host memory on rank 0",
                        "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1),
-                       "scene_create_ms": scene_create_ms,
-                       "wall_clock_per_frame_ms": scene_create_ms + elapsed / args.steps * 1e3},
+                       "rays_are": "the rays the REFERENCE casts for these samples (closest-hit + one shadow ray per hit and light); "
+                                   "shadow rays that can only add zero are not traced here",
+                       "scene_create_ms": wl.scene_create_ms,
+                       "wall_clock_per_frame_ms": wl.scene_create_ms + elapsed / args.steps * 1e3},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        # ---- the other BASELINE configs on the same clock (1 GPU, default invocation only)
+        if default_run and world == 1 and not args.no_other_configs:
+            others = []
+            for name, ospp in OTHER_CONFIGS:
+                t_cfg = time.perf_counter()
+                try:
+                    o = Workload(name, args, 0, 1, local_rank, backend, spp=ospp, is_headline=False)
+                    buf = np.empty(o.W * o.H * 3, dtype=np.float32)
+                    osteps, owarm = 2, 1
+                    for _ in range(owarm):
+                        o.gpu.render_batch_reduce(o.camera, o.params(), root=0, out=buf)
+                        o.step_no += 1
+                    torch.cuda.synchronize()
+                    o.gpu.reset_stats()
+                    t1 = time.perf_counter()
+                    for _ in range(osteps):
+                        o.gpu.render_batch_reduce(o.camera, o.params(), root=0, out=buf)
+                        o.step_no += 1
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    ost = o.gpu.stats()
+                    ob, oosc = accounting(o, ost)
+                    ok, odom, okn = kernel_table(o, ost, ob)
+                    o.gpu.close()
+                    opmc, onote = (None, "--no-live-pmc") if args.no_live_pmc else live_pmc(name, ospp, (PMC_A,))
+                    oroof = roofline_object(o, ost, ok, odom, okn, ob, opmc, onote, ospp)
+                    oroof["kernels"] = {k: {"launches": v["launches"], "avg_ms": v["avg_ms"], "total_ms": v["total_ms"]} for k, v in ok.items()}
+                    ocpu = None if args.no_cpu_baseline else cpu_baseline(o, None, 4.0)
+                    others.append({"workload": "%s %dx%d, %d bounces, %d spp per step" % (name, o.W, o.H, o.B, ospp),
+                                   "value": float(o.W) * o.H * ospp * osteps / dt / 1e6, "unit": "Msamples/s",
+                                   "ms_per_step": dt / osteps * 1e3, "steps": osteps, "warmup": owarm, "spp": ospp,
+                                   "scene_create_ms": o.scene_create_ms,
+                                   "rays_per_s": (ost.extend_rays + ost.shadow_rays) / dt,
+                                   "roofline": oroof, "cpu_baseline": ocpu,
+                                   "wall_s_of_this_entry": None})
+                except Exception as e:  # one config must not cost the bench line
+                    others.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
+                others[-1]["wall_s_of_this_entry"] = time.perf_counter() - t_cfg
+            out["other_configs"] = others
         print(json.dumps(out))
     gpu.close()
     if world > 1:

@@ -334,6 +334,36 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   h->ws_bounces = max_bounces;
 }
 
+// -DRPT_PROF builds (kernels/prof.inc): per phase, the share of the waves' time, the lanes that were active while it
+// ran (lane time / wave time, of 64), and for loop bodies the iteration count and the lanes per iteration.  One line
+// per slot that was used, machine-readable enough to be committed under profiles/ as it is.
+void print_prof(const KernelTable* kt, const char* what) {
+  static const char* const NAMES[24] = {
+      "tree_trace refill", "tree_trace node steps", "tree_trace box tests", "tree_trace pop", "tree_trace write-out",
+      "tree_trace exact tests", "in-kernel node step", "in-kernel box batch", "in-kernel child test",
+      "in-kernel triangle batch", "in-kernel object", "paths fetch", "paths raygen", "paths closest_hit",
+      "paths illuminate", "paths visible", "paths nee_bsdf", "paths sample_f", "paths bsdf", "paths record",
+      "paths fold+store", "flat candidate walk", "fold iteration", "rejection round"};
+  unsigned long long t[4][24];
+  if (!kt->read_prof(t)) return;
+  unsigned long long tot = 0;
+  for (int i = 0; i < 24; i++) tot += t[0][i];
+  std::fprintf(stderr, "prof[%s] %-28s %8s %10s %14s %10s\n", what, "phase", "time %", "lanes/64", "iterations", "lanes/64");
+  for (int i = 0; i < 24; i++) {
+    if (!t[0][i] && !t[2][i]) continue;
+    char a[32] = "-", b[32] = "-", c[32] = "-", d[32] = "-";
+    if (t[0][i]) {
+      std::snprintf(a, sizeof a, "%.2f", tot ? 100.0 * (double)t[0][i] / (double)tot : 0.0);
+      std::snprintf(b, sizeof b, "%.1f", (double)t[1][i] / (double)t[0][i]);
+    }
+    if (t[2][i]) {
+      std::snprintf(c, sizeof c, "%llu", t[2][i]);
+      std::snprintf(d, sizeof d, "%.1f", (double)t[3][i] / (double)t[2][i]);
+    }
+    std::fprintf(stderr, "prof[%s] %-28s %8s %10s %14s %10s\n", what, NAMES[i], a, b, c, d);
+  }
+}
+
 void release_workspace(rptgpu_scene* h) {
   h->ray.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->nrec.release(); h->rec.release();
   h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release();
@@ -450,13 +480,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       unsigned long long rc[16] = {0};
       HIP_TRY(hipMemcpyAsync(rc, h->pcounters.p, sizeof rc, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      if (std::getenv("RPTGPU_PRINT_PHASES")) { // only meaningful with a -DRPT_PHASE_TIMERS build
-        unsigned long long tot = 0;
-        for (int i = 2; i < 14; i++) tot += rc[i];
-        const char* nm[12] = {"fetch", "raygen", "closest_hit", "illuminate", "visible", "nee_bsdf", "sample_f",
-                              "fold+store", "bsdf", "record", "rejoin", "-"};
-        for (int i = 0; i < 12 && tot; i++) std::fprintf(stderr, "phase %-14s %6.2f %%\n", nm[i], 100.0 * rc[2 + i] / tot);
-      }
+      if (std::getenv("RPTGPU_PRINT_PHASES")) print_prof(kt, "rpt_paths");
       h->stats.samples += (uint64_t)npix * p->iterations;
       h->stats.extend_rays += rc[0];
       h->stats.shadow_rays += rc[1];
@@ -555,14 +579,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         HIP_TRY(hipGetLastError()); // a failed launch is reported here, not by the stream sync
       }
       kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
-      if (std::getenv("RPTGPU_PRINT_PHASES")) { // only with a -DRPT_TT_TIMERS build
+      if (std::getenv("RPTGPU_PRINT_PHASES")) {
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long ph[8];
-        if (kt->read_tt_phases(ph)) {
-          const char* nm[6] = {"refill", "node steps", "leaf (boxes + exact)", "pop", "write-out", "  of which exact tests"};
-          unsigned long long tot = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
-          for (int i = 0; i < 6 && tot; i++) std::fprintf(stderr, "tree_trace phase %-24s %6.2f %%\n", nm[i], 100.0 * ph[i] / tot);
-        }
+        print_prof(kt, "wavefront");
       }
     }
     HIP_TRY(hipGetLastError());

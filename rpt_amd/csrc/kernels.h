@@ -69,8 +69,9 @@ struct KernelTable {
                        const double* thr, uint8_t* out);
   void (*buffer_variance)(hipStream_t, const double* total, const double* const* batches, uint32_t nb, uint64_t npix,
                           double* out);
-  // -DRPT_TT_TIMERS builds: per-phase wave cycles of rpt_tree_trace since the last call; false in regular builds
-  bool (*read_tt_phases)(unsigned long long out[8]);
+  // -DRPT_PROF builds: the per-phase table of kernels/prof.inc since the last call ([0] wave cycles, [1] lane cycles,
+  // [2] wave iterations, [3] lane iterations); false in regular builds
+  bool (*read_prof)(unsigned long long out[4][24]);
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)

@@ -423,8 +423,8 @@ def test_bench_two_ranks_equal_one_rank(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "1", "--warmup", "0", "--spp", "4", "--width", "320", "--height", "180", "--no-cpu-baseline",
-              "--fixed-samples"]
+    common = ["--scene", "cornell", "--steps", "1", "--warmup", "0", "--spp", "4", "--width", "320", "--height", "180",
+              "--no-cpu-baseline", "--no-live-pmc", "--fixed-samples"]
     one = str(tmp_path / "one.npy")
     two = str(tmp_path / "two.npy")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-frame", one] + common,
