@@ -29,6 +29,13 @@ struct SortBufs {
   size_t tmp_bytes;
 };
 
+// thresholds of the wave scheduler of rpt_tree_walk (kernels/treewalk.inc), in lanes: node steps run while at least
+// th_node lanes are at inner nodes, exact tests once th_exact lanes hold a candidate, idle lanes fetch new rays once
+// th_refill of them are idle.  Scheduling only: no value changes a result.
+struct WalkTuning {
+  uint32_t th_node, th_exact, th_refill;
+};
+
 // accounting hook of launch_query: called with (ctx, kind, 0) before and (ctx, kind, 1) after the launches of
 // a phase of the query (kind = RPT_K_TREE_TRACE / RPT_K_TREE_SORT); may be null
 struct QueryHook {
@@ -59,7 +66,8 @@ struct KernelTable {
   // object by object with per-tree ray compaction and persistent traversal
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                 int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
-                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook);
+                uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook,
+                const WalkTuning* walk /* null: the lock-step traversal kernel rpt_tree_trace */);
   size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);
