@@ -152,7 +152,9 @@ struct rptgpu_scene {
   int rays_in_kernel = 0;          // RPTGPU_RAYS_IN_KERNEL: rptgpu_closest_hit keeps to rpt_extend_rays also when the scene has deep trees
   DevBuf<uint32_t> tq, tq_ctr;
   bool tree_walk = true;           // RPTGPU_TREE_WALK: deep trees are traversed by rpt_tree_walk (0: the lock-step rpt_tree_trace)
-  WalkTuning walk{20, 12, 16};     // RPTGPU_WALK_TH="node,exact,refill": its scheduler thresholds, in lanes
+  WalkArgs walk{{16, 8, 16}, {}};  // RPTGPU_WALK_TH="node,exact,refill": its scheduler thresholds, in lanes
+  DevBuf<uint32_t> spill_node;     // its traversal-stack spill area (kernels.h StackSpill)
+  DevBuf<double> spill_ts, spill_bmax;
   // optional ray sort in front of the per-tree traversal (RPTGPU_SORT_RAYS)
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
   int sort_mode = -1;              // RPTGPU_SORT_RAYS: 0 never, 1 every deep tree, default: by footprint
@@ -323,6 +325,12 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   if (h->has_deep) {
     h->tq.alloc(3 * cap); // a tree's ray queue | its rays with a zero direction component | those handed to the general form
     h->tq_ctr.alloc(5);
+    { // the traversal grid's stack spill area: one column per thread, KD_MAX_STACK - RPT_TT_LEVELS levels
+      const uint64_t threads = (uint64_t)std::max(1, h->num_cus * 4) / 4 * RPT_TT_WAVES * 256;
+      const uint64_t levels = (uint64_t)(rptdev::KD_MAX_STACK - RPT_TT_LEVELS);
+      h->spill_node.alloc(levels * threads); h->spill_ts.alloc(levels * threads); h->spill_bmax.alloc(levels * threads);
+      h->walk.spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads};
+    }
     if (h->sort_rays) {
       h->sort_kin.alloc(cap); h->sort_kout.alloc(cap); h->sort_vin.alloc(cap);
       size_t bytes = rpt_strict::TABLE.sort_temp_bytes((uint32_t)cap);
@@ -672,7 +680,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     if (const char* e = std::getenv("RPTGPU_WALK_TH")) {
       unsigned a = 0, b = 0, c = 0;
       if (std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3)
-        h->walk = WalkTuning{std::min(64u, std::max(1u, a)), std::min(64u, std::max(1u, b)), std::min(64u, std::max(1u, c))};
+        h->walk.tune = WalkTuning{std::min(64u, std::max(1u, a)), std::min(64u, std::max(1u, b)), std::min(64u, std::max(1u, c))};
     }
     if (const char* e = std::getenv("RPTGPU_RAYS_IN_KERNEL")) h->rays_in_kernel = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_RAYS")) h->sort_mode = std::atoi(e) != 0 ? 1 : 0;

@@ -35,6 +35,26 @@ struct SortBufs {
 struct WalkTuning {
   uint32_t th_node, th_exact, th_refill;
 };
+// waves per SIMD of the per-tree traversal kernels and the stack levels they keep in LDS
+// (RPT_TT_WAVES * 4 * 64 lanes * 20 B * levels <= 160 KB per CU); deeper levels go to the spill area
+#ifndef RPT_TT_WAVES
+#define RPT_TT_WAVES 4
+#endif
+#ifndef RPT_TT_LEVELS
+#define RPT_TT_LEVELS 7
+#endif
+// spill area of the traversal stack beyond the LDS levels: [KD_MAX_STACK - RPT_TT_LEVELS][threads] per array, one
+// column per thread of the traversal grid (api.cpp allocates it for scenes with deep trees)
+struct StackSpill {
+  uint32_t* node;
+  double* ts;
+  double* bmax;
+  uint32_t threads;
+};
+struct WalkArgs {
+  WalkTuning tune;
+  StackSpill spill;
+};
 
 // accounting hook of launch_query: called with (ctx, kind, 0) before and (ctx, kind, 1) after the launches of
 // a phase of the query (kind = RPT_K_TREE_TRACE / RPT_K_TREE_SORT); may be null
@@ -67,7 +87,7 @@ struct KernelTable {
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                 int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
                 uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook,
-                const WalkTuning* walk /* null: the lock-step traversal kernel rpt_tree_trace */);
+                const WalkArgs* walk /* null: the lock-step traversal kernel rpt_tree_trace */);
   size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);

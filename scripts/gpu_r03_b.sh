@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, call b: rpt_tree_walk (wave-scheduled traversal) — parity, A/B against rpt_tree_trace, threshold sweep
 cd ${GRAFT_REPO_ROOT:-.}
-O=gpurun_out/r03b; mkdir -p $O
+O=gpurun_out/r03c; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 run() { # scene spp label env...
@@ -14,7 +14,7 @@ print('$sc','$lab',round(d['value'],1),'tt',round(k.get('rpt_tree_trace',{}).get
 for sc in "dragon 32" "wine_glass 8"; do
   set -- $sc
   run $1 $2 old RPTGPU_TREE_WALK=0
-  for th in 20,12,16 16,8,16 24,16,16 32,16,16 12,8,16 20,12,8 20,12,32 20,24,16 20,4,16 28,12,24 8,1,56; do
+  for th in 16,8,16 20,12,16 12,8,16 12,4,24 8,1,56 16,8,32 24,8,16 16,16,16; do
     run $1 $2 walk_$th RPTGPU_WALK_TH=$th
   done
 done
