@@ -151,9 +151,8 @@ struct rptgpu_scene {
   bool has_deep = false;
   int rays_in_kernel = 0;          // RPTGPU_RAYS_IN_KERNEL: rptgpu_closest_hit keeps to rpt_extend_rays also when the scene has deep trees
   DevBuf<uint32_t> tq, tq_ctr;
-  bool tree_walk = true;           // RPTGPU_TREE_WALK: deep trees are traversed by rpt_tree_walk (0: the lock-step rpt_tree_trace)
-  WalkArgs walk{{16, 8, 16}, {}};  // RPTGPU_WALK_TH="node,exact,refill": its scheduler thresholds, in lanes
-  DevBuf<uint32_t> spill_node;     // its traversal-stack spill area (kernels.h StackSpill)
+  StackSpill spill{};              // the per-tree traversal kernels' stack beyond the LDS levels (kernels.h)
+  DevBuf<uint32_t> spill_node;
   DevBuf<double> spill_ts, spill_bmax;
   // optional ray sort in front of the per-tree traversal (RPTGPU_SORT_RAYS)
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
@@ -329,7 +328,7 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
       const uint64_t threads = (uint64_t)std::max(1, h->num_cus * 4) / 4 * RPT_TT_WAVES * 256;
       const uint64_t levels = (uint64_t)(rptdev::KD_MAX_STACK - RPT_TT_LEVELS);
       h->spill_node.alloc(levels * threads); h->spill_ts.alloc(levels * threads); h->spill_bmax.alloc(levels * threads);
-      h->walk.spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads};
+      h->spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads};
     }
     if (h->sort_rays) {
       h->sort_kin.alloc(cap); h->sort_kout.alloc(cap); h->sort_vin.alloc(cap);
@@ -555,7 +554,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           { Bracket b(h, RPT_K_EXTEND, prof);
             if (by_object)
               kt->query(st, h->dscene, ps, queue, n_active, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
-                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, h->tree_walk ? &h->walk : nullptr);
+                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill);
             else
               kt->extend(st, h->dscene, ps, queue, n_active);
             b.done(); }
@@ -569,7 +568,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
               for (int l = 0; l < h->dscene.num_lights; l++)
                 if (h->light_casts[l])
                   kt->query(st, h->dscene, ps, queue, n_active, l, h->srt.p, h->obj_deep.data(), h->obj_tris.data(),
-                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, h->tree_walk ? &h->walk : nullptr);
+                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill);
               kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
             } else {
               kt->shadow(st, h->dscene, ps, queue, n_active, depth);
@@ -676,12 +675,6 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->prefer_wavefront = fs.max_tree_depth >= 3;
     uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
     if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RPTGPU_TREE_WALK")) h->tree_walk = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RPTGPU_WALK_TH")) {
-      unsigned a = 0, b = 0, c = 0;
-      if (std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3)
-        h->walk.tune = WalkTuning{std::min(64u, std::max(1u, a)), std::min(64u, std::max(1u, b)), std::min(64u, std::max(1u, c))};
-    }
     if (const char* e = std::getenv("RPTGPU_RAYS_IN_KERNEL")) h->rays_in_kernel = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_RAYS")) h->sort_mode = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_MIN_BYTES")) h->sort_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
@@ -957,7 +950,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
         for (int k = 0; k < 6; k++)
           HIP_TRY(hipMemcpyAsync(ps.ray + (uint64_t)k * ps.cap, soa.data() + (uint64_t)k * m, m * sizeof(double), hipMemcpyHostToDevice, st));
         kt->query(st, h->dscene, ps, nullptr, (uint32_t)m, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
-                  h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, nullptr, h->tree_walk ? &h->walk : nullptr);
+                  h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, nullptr, &h->spill);
         HIP_TRY(hipGetLastError());
         for (int k = 0; k < 4; k++)
           HIP_TRY(hipMemcpyAsync(hit.data() + (uint64_t)k * m, ps.hit + (uint64_t)k * ps.cap, m * sizeof(double), hipMemcpyDeviceToHost, st));

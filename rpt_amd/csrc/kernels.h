@@ -29,12 +29,6 @@ struct SortBufs {
   size_t tmp_bytes;
 };
 
-// thresholds of the wave scheduler of rpt_tree_walk (kernels/treewalk.inc), in lanes: node steps run while at least
-// th_node lanes are at inner nodes, exact tests once th_exact lanes hold a candidate, idle lanes fetch new rays once
-// th_refill of them are idle.  Scheduling only: no value changes a result.
-struct WalkTuning {
-  uint32_t th_node, th_exact, th_refill;
-};
 // waves per SIMD of the per-tree traversal kernels and the stack levels they keep in LDS
 // (RPT_TT_WAVES * 4 * 64 lanes * 20 B * levels <= 160 KB per CU); deeper levels go to the spill area
 #ifndef RPT_TT_WAVES
@@ -50,10 +44,6 @@ struct StackSpill {
   double* ts;
   double* bmax;
   uint32_t threads;
-};
-struct WalkArgs {
-  WalkTuning tune;
-  StackSpill spill;
 };
 
 // accounting hook of launch_query: called with (ctx, kind, 0) before and (ctx, kind, 1) after the launches of
@@ -87,7 +77,7 @@ struct KernelTable {
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                 int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
                 uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook,
-                const WalkArgs* walk /* null: the lock-step traversal kernel rpt_tree_trace */);
+                const StackSpill* spill /* the traversal stack beyond the LDS levels */);
   size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);
