@@ -379,6 +379,12 @@ struct Flattener {
       t.sample_zone = 0xFFFFFFFFFFFFFFFFull - (0xFFFFFFFFFFFFFFFFull - n + 1) % n;
     }
     t.regular = kb.regular ? 1u : 0u;
+    t.split_range_ok = t.regular;
+    for (const rptdev::KdNode& nd : kb.nodes) {
+      if ((nd.ib & 3u) == 3u) continue;
+      const double a = std::fabs(nd.split);
+      if (!(a == 0.0 || (a >= 0x1p-340 && a < 0x1p399))) t.split_range_ok = 0u;
+    }
     if (!kb.nodes.empty() && (kb.nodes[0].ib & 3u) == 3u) {
       t.root_leaf = 1u + (kb.nodes[0].ib >> 2);
       t.root_first = kb.nodes[0].a;

@@ -1,22 +1,20 @@
 #!/bin/bash
-# generic A/B: scripts/gpu_ab.sh <outdir> "<ENV=val ENV2=val2|...>" "scene:spp scene:spp" [pytest]
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $REPO
+# A/B of library variants on the GPU box:  bash scripts/gpu_ab.sh <outdir> "<scene spp> ..." "<variant> ..."   (variant "base" = librptgpu.so)
+# prints one line per (scene, variant): Msamples/s and the ms of the main kernels; repeats each measurement REP times (default 2)
+cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/$1; mkdir -p $O
-if [ "${4:-}" = "pytest" ]; then
-  timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
-fi
-IFS='|' read -ra ENVS <<< "$2"
-for e in "${ENVS[@]}"; do
-  for cfg in $3; do
-    sc=${cfg%%:*}; spp=${cfg##*:}
-    tag=$(echo "$e" | tr ' =/' '___')
-    env $e timeout 300 python bench.py --scene $sc --spp $spp --steps 2 --no-cpu-baseline > $O/bench_${sc}_$tag.json 2> $O/bench_${sc}_$tag.err
-    python -c "
-import json
+export TMPDIR=/tmp
+REP=${REP:-2}
+for sc in $2; do
+  scene=${sc%%:*}; spp=${sc##*:}
+  for r in $(seq $REP); do
+  for v in $3; do
+    if [ "$v" = base ]; then L=$PWD/rpt_amd/lib/librptgpu.so; else L=$PWD/rpt_amd/lib/librptgpu_$v.so; fi
+    RPTGPU_LIB=$L timeout 300 python bench.py --scene $scene --steps 2 --warmup 1 --spp $spp --no-cpu-baseline --no-live-pmc 2>$O/err_${scene}_$v.txt | python -c "
+import sys,json
 try:
-    d=json.loads(open('$O/bench_${sc}_$tag.json').read().strip().splitlines()[-1]); k=d['roofline']['kernels']
-    print('%-28s %-16s %7.1f Msamples/s' % ('$e', '$sc', d['value']), {n:round(v['total_ms'],1) for n,v in k.items()})
-except Exception as ex: print('$e $sc FAILED', ex)"
-  done
-done 2>&1 | tee -a $O/ab.txt
+    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels']
+    print('$scene','$v',round(d['value'],1),' '.join('%s=%.1f'%(n.replace('rpt_',''),k[n]['total_ms']) for n in k if k[n]['total_ms']>=1.0))
+except Exception as e: print('$scene','$v','FAILED',e)" | tee -a $O/ab.txt
+  done; done
+done
