@@ -220,7 +220,10 @@ typedef struct RptStats {
   double kernel_ms[RPT_K_COUNT];        /* summed HIP-event time per kernel kind             */
   uint64_t kernel_launches[RPT_K_COUNT];
   uint64_t extend_rays;  /* closest-hit rays traced  (get_closest_hit, renderer.rs:146)      */
-  uint64_t shadow_rays;  /* shadow rays traced       (renderer.rs:191-196)                   */
+  uint64_t shadow_rays;  /* shadow rays the REFERENCE casts for these samples: one per hit and non-ambient
+                            light (renderer.rs:191-196)                                       */
+  uint64_t shadow_rays_traced; /* of those, the ones actually traversed: a light that can only add exactly zero
+                            (bsdf = 0 below an opaque surface, a light sample facing away) needs no ray  */
   uint64_t samples;      /* camera paths started                                             */
   double total_ms;       /* wall time inside rptgpu_render_batch* (host clock)                */
 } RptStats;

@@ -100,7 +100,7 @@ class RptRenderParams(C.Structure):
 
 class RptStats(C.Structure):
     _fields_ = [("kernel_ms", f64 * RPT_K_COUNT), ("kernel_launches", C.c_uint64 * RPT_K_COUNT),
-                ("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shadow_rays_traced", C.c_uint64),
                 ("samples", C.c_uint64), ("total_ms", f64)]
 
 

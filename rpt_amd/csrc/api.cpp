@@ -148,6 +148,7 @@ struct rptgpu_scene {
   bool ext_shapes = false;       // scene has a shape only the *_ext kernel builds implement
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
+  std::vector<uint32_t> cnt_host;  // the per-depth counters read back from the device
   bool has_deep = false;
   int rays_in_kernel = 0;          // RPTGPU_RAYS_IN_KERNEL: rptgpu_closest_hit keeps to rpt_extend_rays also when the scene has deep trees
   DevBuf<uint32_t> tq, tq_ctr;
@@ -162,6 +163,7 @@ struct rptgpu_scene {
   DevBuf<uint8_t> sort_tmp;
   SortBufs sort_bufs{};
   DevBuf<double> srt;
+  DevBuf<uint32_t> shadow_q;
   // cached pixel partition
   uint32_t part_key[6] = {0, 0, 0, 0, 0, 0};
   uint32_t npix = 0;
@@ -320,7 +322,11 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   h->shadow.alloc((uint64_t)nl * rptdev::SHADOW_FIELDS * cap);
   h->queue_a.alloc(cap);
   h->queue_b.alloc(cap);
-  h->counters.alloc(4);
+  h->counters.alloc(2 + (size_t)nl); // [0] next-depth paths, [1] hits, [2 + l] shadow rays queued for light l
+  h->shadow_q.release();
+  h->shadow_q.alloc((uint64_t)nl * cap); // per light: the paths that cast a shadow ray towards it at the current depth
+  h->srt.release();
+  h->srt.alloc((uint64_t)nl * cap);      // per light and path: record.time of the shadow ray (rpt_shadow_sum reads it)
   if (h->has_deep) {
     h->tq.alloc(3 * cap); // a tree's ray queue | its rays with a zero direction component | those handed to the general form
     h->tq_ctr.alloc(5);
@@ -336,8 +342,6 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
       h->sort_tmp.alloc(bytes);
       h->sort_bufs = SortBufs{h->sort_kin.p, h->sort_kout.p, h->sort_vin.p, h->sort_tmp.p, bytes};
     }
-    h->srt.release();
-    h->srt.alloc((uint64_t)nl * cap);
   }
   h->ws_cap = cap;
   h->ws_bounces = max_bounces;
@@ -375,7 +379,7 @@ void print_prof(const KernelTable* kt, const char* what) {
 
 void release_workspace(rptgpu_scene* h) {
   h->ray.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->nrec.release(); h->rec.release();
-  h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release();
+  h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
   h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release();
   h->ws_cap = 0; h->ws_bounces = 0;
 }
@@ -493,6 +497,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       h->stats.samples += (uint64_t)npix * p->iterations;
       h->stats.extend_rays += rc[0];
       h->stats.shadow_rays += rc[1];
+      h->stats.shadow_rays_traced += rc[1]; // the persistent kernel traces every shadow ray (a skip there saves no wave time)
     } else if (npix) {
       // Paths in flight per pass.  Late bounces keep few paths alive, and a depth's kernels need ~10^5 rays to fill
       // 256 CUs, so the more paths start together the better the deep bounces run (C3 stand-in: 4 Mi -> 71, 16 Mi ->
@@ -502,7 +507,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       if (!target) {
         const uint64_t nl = (uint64_t)std::max(1, h->dscene.num_lights);
         uint64_t per_path = 6 * 8 + 4 * 8 + 4 + 4 + 1 + (uint64_t)(p->max_bounces + 1) * rptdev::REC_FIELDS * 8 +
-                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + (h->has_deep ? 12 + nl * 8 + (h->sort_rays ? 12 + 16 : 0) : 0);
+                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + nl * (8 + 4) + (h->has_deep ? 12 + (h->sort_rays ? 12 + 16 : 0) : 0);
         uint64_t budget = h->ws_budget_bytes;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -553,31 +558,38 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           const uint32_t trace_blocks = (uint32_t)std::max(1, h->num_cus * 4);
           { Bracket b(h, RPT_K_EXTEND, prof);
             if (by_object)
-              kt->query(st, h->dscene, ps, queue, n_active, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
+              kt->query(st, h->dscene, ps, queue, n_active, -1, nullptr, nullptr, h->obj_deep.data(), h->obj_tris.data(),
                         h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill);
             else
               kt->extend(st, h->dscene, ps, queue, n_active);
             b.done(); }
           h->stats.extend_rays += n_active;
-          HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(uint32_t), st));
+          const int nl = h->dscene.num_lights;
+          HIP_TRY(hipMemsetAsync(h->counters.p, 0, (2 + (size_t)nl) * sizeof(uint32_t), st));
           { Bracket b(h, RPT_K_SHADE, prof);
-            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, h->counters.p); b.done(); }
+            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, h->counters.p, h->shadow_q.p, h->counters.p + 2); b.done(); }
           if (any_lights) {
+            // the visibility queries run over rpt_shade's per-light shadow-ray queues; their lengths stay on the device
+            // (the launches are sized for n_active, the host's bound) and are read back with the depth's other counters
             Bracket b(h, RPT_K_SHADOW, prof);
             if (by_object) {
-              for (int l = 0; l < h->dscene.num_lights; l++)
+              for (int l = 0; l < nl; l++)
                 if (h->light_casts[l])
-                  kt->query(st, h->dscene, ps, queue, n_active, l, h->srt.p, h->obj_deep.data(), h->obj_tris.data(),
+                  kt->query(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, n_active, l, h->srt.p, h->counters.p + 2 + l, h->obj_deep.data(), h->obj_tris.data(),
                             h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill);
-              kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
             } else {
-              kt->shadow(st, h->dscene, ps, queue, n_active, depth);
+              for (int l = 0; l < nl; l++)
+                if (h->light_casts[l])
+                  kt->shadow_rays(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, h->counters.p + 2 + l, n_active, l, h->srt.p);
             }
+            kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
             b.done();
           }
-          uint32_t cnt[2] = {0, 0};
-          HIP_TRY(hipMemcpyAsync(cnt, h->counters.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+          h->cnt_host.resize(2 + (size_t)nl);
+          uint32_t* cnt = h->cnt_host.data();
+          HIP_TRY(hipMemcpyAsync(cnt, h->counters.p, (2 + (size_t)nl) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
+          for (int l = 0; l < nl; l++) h->stats.shadow_rays_traced += cnt[2 + l];
           if (prof && h->pending.size() >= 256) drain_events(h); // the stream is idle here: cheap
           h->stats.shadow_rays += (uint64_t)cnt[1] * (uint64_t)h->dscene.num_shadow_lights;
           n_active = cnt[0];
@@ -949,7 +961,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
           }
         for (int k = 0; k < 6; k++)
           HIP_TRY(hipMemcpyAsync(ps.ray + (uint64_t)k * ps.cap, soa.data() + (uint64_t)k * m, m * sizeof(double), hipMemcpyHostToDevice, st));
-        kt->query(st, h->dscene, ps, nullptr, (uint32_t)m, -1, nullptr, h->obj_deep.data(), h->obj_tris.data(),
+        kt->query(st, h->dscene, ps, nullptr, (uint32_t)m, -1, nullptr, nullptr, h->obj_deep.data(), h->obj_tris.data(),
                   h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, nullptr, &h->spill);
         HIP_TRY(hipGetLastError());
         for (int k = 0; k < 4; k++)
@@ -1238,7 +1250,7 @@ const char* rptgpu_kernel_name(int k) {
     case RPT_K_RAYGEN: return "rpt_raygen";
     case RPT_K_EXTEND: return "rpt_extend";
     case RPT_K_SHADE: return "rpt_shade";
-    case RPT_K_SHADOW: return "rpt_shadow";
+    case RPT_K_SHADOW: return "rpt_shadow"; // the visibility queries of a depth: rpt_shadow_rays or the per-tree kernels, + rpt_shadow_sum
     case RPT_K_RESOLVE: return "rpt_resolve";
     case RPT_K_PATHS: return "rpt_paths";
     case RPT_K_TREE_TRACE: return "rpt_tree_trace";

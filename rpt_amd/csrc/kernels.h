@@ -58,10 +58,13 @@ struct KernelTable {
   void (*extend)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n);
   void (*extend_rays)(hipStream_t, const rptdev::Scene&, const double* o, const double* d, uint64_t n, double* out_t,
                       double* out_n, int32_t* out_obj);
+  // sq / sq_count: per light, the queue of the paths that cast a shadow ray towards it and its length ([light][cap], [light])
   void (*shade)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::PathState&,
-                const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters);
-  void (*shadow)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
-                 uint32_t depth);
+                const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters,
+                uint32_t* sq, uint32_t* sq_count);
+  // visibility of one light over its shadow-ray queue, whole scene in the kernel (scenes without deep trees)
+  void (*shadow_rays)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* sq,
+                      const uint32_t* sq_count, uint32_t n, int light, double* srt);
   void (*resolve)(hipStream_t, const rptdev::Frame&, const rptdev::PathState&, uint32_t n_samples);
   void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32);
   void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
@@ -75,7 +78,7 @@ struct KernelTable {
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run
   // object by object with per-tree ray compaction and persistent traversal
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
-                int light, double* srt, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
+                int light, double* srt, const uint32_t* n_dev /* light >= 0: the device-side length of `queue` */, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
                 uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook,
                 const StackSpill* spill /* the traversal stack beyond the LDS levels */);
   size_t (*sort_temp_bytes)(uint32_t n);

@@ -184,6 +184,7 @@ pub mod ffi {
         pub kernel_launches: [u64; 8],
         pub extend_rays: u64,
         pub shadow_rays: u64,
+        pub shadow_rays_traced: u64,
         pub samples: u64,
         pub total_ms: f64,
     }
@@ -516,7 +517,7 @@ impl GpuScene {
     }
 
     pub fn stats(&self) -> Result<RptStats, GpuError> {
-        let mut s = RptStats { kernel_ms: [0.0; 8], kernel_launches: [0; 8], extend_rays: 0, shadow_rays: 0, samples: 0, total_ms: 0.0 };
+        let mut s = RptStats { kernel_ms: [0.0; 8], kernel_launches: [0; 8], extend_rays: 0, shadow_rays: 0, shadow_rays_traced: 0, samples: 0, total_ms: 0.0 };
         // SAFETY: out-pointer to a local
         check(unsafe { ffi::rptgpu_get_stats(self.h, &mut s) }, self.h)?;
         Ok(s)
@@ -555,7 +556,7 @@ mod layout_tests {
         assert_eq!(size_of::<RptScene>(), 80);
         assert_eq!(size_of::<RptCamera>(), 96);
         assert_eq!(size_of::<RptRenderParams>(), 64);
-        assert_eq!(size_of::<RptStats>(), 160);
+        assert_eq!(size_of::<RptStats>(), 168);
         assert_eq!(size_of::<RptKdTree>(), 64);
     }
 
