@@ -567,7 +567,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           const int nl = h->dscene.num_lights;
           HIP_TRY(hipMemsetAsync(h->counters.p, 0, (2 + (size_t)nl) * sizeof(uint32_t), st));
           { Bracket b(h, RPT_K_SHADE, prof);
-            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, h->counters.p, h->shadow_q.p, h->counters.p + 2); b.done(); }
+            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, h->counters.p, h->shadow_q.p); b.done(); }
           if (any_lights) {
             // the visibility queries run over rpt_shade's per-light shadow-ray queues; their lengths stay on the device
             // (the launches are sized for n_active, the host's bound) and are read back with the depth's other counters

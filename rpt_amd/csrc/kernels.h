@@ -58,10 +58,9 @@ struct KernelTable {
   void (*extend)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n);
   void (*extend_rays)(hipStream_t, const rptdev::Scene&, const double* o, const double* d, uint64_t n, double* out_t,
                       double* out_n, int32_t* out_obj);
-  // sq / sq_count: per light, the queue of the paths that cast a shadow ray towards it and its length ([light][cap], [light])
+  // counters: [0] paths of the next depth, [1] hits, [2 + l] shadow rays queued for light l; sq: those queues ([light][cap])
   void (*shade)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::PathState&,
-                const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters,
-                uint32_t* sq, uint32_t* sq_count);
+                const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters, uint32_t* sq);
   // visibility of one light over its shadow-ray queue, whole scene in the kernel (scenes without deep trees)
   void (*shadow_rays)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* sq,
                       const uint32_t* sq_count, uint32_t n, int light, double* srt);
