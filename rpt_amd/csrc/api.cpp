@@ -721,12 +721,19 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       uint64_t off = 0;
       FlatLayout lay{};
       lay.n_refs = (uint32_t)fs.refs.size();
-      lay.n_tris = (uint32_t)fs.tris.size();
-      off = up16(fs.refs.size() * sizeof(rptdev::TriX));
-      lay.off_tris = (uint32_t)off; off = up16(off + fs.tris.size() * sizeof(rptdev::Tri));
-      lay.off_refs = (uint32_t)off; off = up16(off + fs.refs.size() * sizeof(uint32_t));
-      lay.off_mat = (uint32_t)off;  off = up16(off + (uint64_t)fs.num_objects * sizeof(rptdev::Material));
-      lay.off_leaf = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 16);
+      // intersection records, leaf entries and materials are what a query reads; the triangles themselves (vertex
+      // normals of the hit that stands, light sampling) join them only if everything still fits — C2 does (12
+      // triangles), a room of 23 polygons keeps them in global memory and is flat all the same
+      auto assign = [&](bool with_tris) {
+        lay.n_tris = with_tris ? (uint32_t)fs.tris.size() : 0u;
+        off = up16(fs.refs.size() * sizeof(rptdev::TriX));
+        lay.off_tris = (uint32_t)off; off = up16(off + (uint64_t)lay.n_tris * sizeof(rptdev::Tri));
+        lay.off_refs = (uint32_t)off; off = up16(off + fs.refs.size() * sizeof(uint32_t));
+        lay.off_mat = (uint32_t)off;  off = up16(off + (uint64_t)fs.num_objects * sizeof(rptdev::Material));
+        lay.off_leaf = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 16);
+      };
+      assign(true);
+      if (off + 12 * 64 * sizeof(double) + REC_LEVEL > WAVE_LDS || std::getenv("RPTGPU_FLAT_TRIS_GLOBAL")) assign(false); // (room for the plane table and one record level)
       // shared slab quotients: distinct plane coordinates per axis over the untransformed meshes (bitwise
       // distinct: -0.0 and 0.0 give differently signed zeros), at most 4 per axis or the feature stays off
       std::vector<double> planes(12, 0.0);
