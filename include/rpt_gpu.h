@@ -77,13 +77,20 @@ enum {
   RPT_SHAPE_CUBE = 2,   /* src/shape/cube.rs:8      unit cube [-0.5,0.5]^3                    */
   RPT_SHAPE_MESH = 3,   /* src/shape/mesh.rs:102    Mesh = KdTree<Triangle>                   */
   RPT_SHAPE_GROUP = 4,  /* KdTree<Box<dyn Bounded>> (examples/fractal_spheres.rs:45,
-                           fractal_teapots.rs:69); children must be SPHERE, CUBE or MESH, each
-                           optionally Transformed; MESH children that share one triangle array
-                           (Arc<Mesh>) share one tree on the device                           */
+                           fractal_teapots.rs:69).  Children: anything Bounded — SPHERE, CUBE, MESH,
+                           MONOMIAL, or another GROUP — each optionally Transformed (a PLANE is not
+                           Bounded, kdtree.rs:9-12, and is refused).  MESH children that share one
+                           triangle array (Arc<Mesh>) share one tree on the device.  NESTING: a GROUP may
+                           contain GROUPs whose own children are not GROUPs (scene -> group -> group ->
+                           mesh / primitive); a third group level returns RPTGPU_E_UNSUPPORTED_SHAPE.
+                           The reference nests without bound (kdtree.rs:14-24 forwards Bounded through
+                           Box); on the device every level is one more copy of the traversal inlined into
+                           every kernel that walks a group (registers, code size, minutes of compile
+                           time), so the depth is fixed at what the reference's examples use plus one */
   RPT_SHAPE_MONOMIAL = 5 /* src/shape/monomial_surface.rs:12-18  y = height*(x^2+z^2)^(exp/2),
                             x^2+z^2 <= 1; like the reference, intersection and normals are
-                            only valid for exp = 4 (monomial_surface.rs:10); top-level objects
-                            and Light::Object only                                            */
+                            only valid for exp = 4 (monomial_surface.rs:10): any other exp is
+                            refused.  As a top-level object, a Light::Object, or a GROUP child  */
 };
 
 typedef struct RptShape {

@@ -663,6 +663,15 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
   rpthost::FlatScene fs;
   std::string err;
   int rc;
+  // RPTGPU_PRINT_CREATE=1: where the hand-off's time goes (stderr), for the scene-per-frame use case
+  const bool print_create = std::getenv("RPTGPU_PRINT_CREATE") != nullptr;
+  auto tc0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!print_create) return;
+    auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "scene_create %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tc0).count());
+    tc0 = t;
+  };
   try {
     rc = rpthost::flatten_scene(*scene, fs, err); // validates shapes before touching the GPU
   } catch (const std::bad_alloc&) {
@@ -671,6 +680,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "unexpected exception while flattening");
   }
   if (rc != RPTGPU_OK) return fail(nullptr, rc, err);
+  lap("flatten + kd build");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, RPTGPU_E_NO_DEVICE, "no HIP device is visible (hipGetDeviceCount); there is no CPU fallback");
@@ -684,6 +694,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     h->num_cus = prop.multiProcessorCount;
+    lap("device, stream, properties");
     h->prefer_wavefront = fs.max_tree_depth >= 3;
     uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
     if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
@@ -788,6 +799,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         h->flat_layout = lay;
       }
     }
+    lap("pipeline choice, flat layout");
     h->ext_shapes = fs.nested_mesh;
     for (const rptdev::Inst& in : fs.insts) h->ext_shapes = h->ext_shapes || in.kind == RPT_SHAPE_MONOMIAL;
     for (const rptdev::Light& l : fs.lights) h->light_casts.push_back(l.kind != RPT_LIGHT_AMBIENT ? 1 : 0);
@@ -802,6 +814,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->lights.upload(fs.lights, h->stream);
     h->env_texels.upload(fs.env_texels, h->stream);
     HIP_TRY(hipStreamSynchronize(h->stream));
+    lap("device allocation + upload");
     rptdev::Scene& d = h->dscene;
     d.insts = h->insts.p; d.trees = h->trees.p; d.nodes = h->nodes.p; d.refs = h->refs.p; d.tris = h->tris.p; d.lrec = h->trix.p; d.lbox = h->lbox.p;
     d.materials = h->materials.p; d.lights = h->lights.p; d.env_texels = h->env_texels.p;
