@@ -462,6 +462,11 @@ def main():
     # RPT_BENCH_BACKEND=gloo lets the N>1 logic be exercised with several ranks on ONE GPU
     # (ranks share device local_rank % device_count); the driver's runs use nccl = RCCL.
     backend = os.environ.get("RPT_BENCH_BACKEND", "nccl")
+    # test hooks (tests/test_gpu_parity.py): make ONE rank's library collective unavailable, and try the library
+    # collective under the gloo stand-in too, so that the fall-back below runs without eight GPUs
+    if os.environ.get("RPT_BENCH_FAIL_COMM_RANK", "") == str(rank):
+        os.environ["RPTGPU_FAIL_COMM"] = "1"
+    force_lib = os.environ.get("RPT_BENCH_FORCE_LIB_COLLECTIVE", "") == "1"
     local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -483,7 +488,8 @@ def main():
     # The collective lives in the library (rptgpu_comm_init / rptgpu_render_batch_reduce: ncclReduce on the library's
     # stream, then D2H on rank 0), so no torch op sits in the timed path.  Only the gloo stand-in used by the tests
     # (several ranks sharing one GPU, which RCCL refuses) goes through torch.distributed.
-    lib_collective = world == 1 or backend == "nccl"
+    lib_collective = world == 1 or backend == "nccl" or force_lib
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the few control-plane tensors of the set-up live
     collective_note = None
     if lib_collective and world > 1:
         # Step 1, local and cheap: can THIS rank open RCCL from the library at all?  Agreed on by every rank BEFORE anyone
@@ -493,17 +499,17 @@ def main():
             rpt_amd.GpuScene.comm_unique_id()
         except Exception as e:
             ok, collective_note = 0, "%s: %s" % (type(e).__name__, e)
-        agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+        agreed = torch.tensor([ok], dtype=torch.int32, device=cdev)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         if int(agreed.item()) == 1:
             # Step 2: the communicator.  ncclCommInitRank either succeeds or fails on every rank (it is itself a rendezvous)
             try:
                 uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0, device=dev)
+                dist.broadcast_object_list(uid, src=0, device=cdev)
                 gpu.comm_init(rank, world, uid[0])
             except Exception as e:
                 ok, collective_note = 0, "%s: %s" % (type(e).__name__, e)
-            agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+            agreed = torch.tensor([ok], dtype=torch.int32, device=cdev)
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         if int(agreed.item()) == 0:  # say why, and let torch's RCCL do the reduce
             if ok:

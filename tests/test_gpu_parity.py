@@ -443,6 +443,39 @@ def test_bench_two_ranks_equal_one_rank(tmp_path):
     assert a.shape == b.shape == (320 * 180 * 3,) and (a == b).all() and a.max() > 0
 
 
+@pytest.mark.parametrize("failing_rank", ["1", "all"])
+def test_bench_two_ranks_fall_back_when_the_library_collective_is_unavailable(tmp_path, failing_rank):
+    """The set-up of the library's RCCL collective in bench.py, exercised without eight GPUs: two ranks (gloo stand-in,
+    both on device 0) are told to try the library collective (RPT_BENCH_FORCE_LIB_COLLECTIVE), and one rank — or every
+    rank — finds RCCL unavailable (RPTGPU_FAIL_COMM through RPT_BENCH_FAIL_COMM_RANK).  The ranks must agree on that
+    BEFORE anyone enters ncclCommInitRank (a rank that cannot would leave the others blocked in the rendezvous), say
+    why on the line they print, reduce through torch.distributed instead, and produce the single-rank frame."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--scene", "cornell", "--steps", "1", "--warmup", "0", "--spp", "4", "--width", "320", "--height", "180",
+              "--no-cpu-baseline", "--no-live-pmc", "--fixed-samples"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-frame", one] + common,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, RPT_BENCH_BACKEND="gloo", RPT_BENCH_FORCE_LIB_COLLECTIVE="1")
+    if failing_rank == "all":
+        env["RPTGPU_FAIL_COMM"] = "1"
+    else:
+        env["RPT_BENCH_FAIL_COMM_RANK"] = failing_rank
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--dump-frame", two] + common, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and "could not be set up" in out["config"]["collective"], out["config"]["collective"]
+    assert "RPTGPU_FAIL_COMM" in out["config"]["collective"]
+    a, b = np.load(one), np.load(two)
+    assert (a == b).all() and a.max() > 0
+
+
 def test_edge_cases_match_the_oracle(oracle):
     """Small / degenerate configurations, every one compared bit for bit with the oracle."""
     cases = []
