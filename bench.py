@@ -205,7 +205,8 @@ def live_pmc(scene, spp, passes, extra=(), timeout=150):
                 c = sqlite3.connect(dbs[0])
                 for k, cn, total in c.execute("select kernel_name, counter_name, sum(value) from counters_collection "
                                               "group by kernel_name, counter_name"):
-                    raw.setdefault(short_kernel(k), {})[cn] = total
+                    d_k = raw.setdefault(short_kernel(k), {})  # template variants of a kernel kind share the short name
+                    d_k[cn] = d_k.get(cn, 0.0) + total
                 if i == 0:  # the kernels' durations INSIDE the counter run (microseconds), the denominator of its byte rates
                     for name, tot in c.execute("select name, total_duration from top_kernels"):
                         dur[short_kernel(name)] = dur.get(short_kernel(name), 0.0) + tot

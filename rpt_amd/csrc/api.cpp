@@ -415,6 +415,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
   auto t0 = std::chrono::steady_clock::now();
   try {
     HIP_TRY(hipSetDevice(h->device));
+    // hipGetLastError() reports the thread's LAST failed runtime call, whoever made it (another library in the process,
+    // an unchecked clean-up call): start from a clean slate so that the checks below speak about this call's launches
+    (void)hipGetLastError();
     hipStream_t st = h->stream;
     const KernelTable* kt = table_for(p->precision_mode, h->ext_shapes);
     const bool prof = (p->flags & RPT_FLAG_PROFILE_KERNELS) != 0;
