@@ -133,6 +133,7 @@ SYMBOLS = [
      [_VP, C.c_uint64, _PD, _PD, C.c_uint32, _PD, _PD, C.POINTER(C.c_int32)]),
     ("rptgpu_eval_math", C.c_int, [_VP, C.c_int, C.c_uint64, _PD, _PD, _PD]),
     ("rptgpu_kdtree_build", C.c_int, [_PD, C.c_uint64, C.POINTER(RptKdTree)]),
+    ("rptgpu_kdtree_build_device", C.c_int, [_PD, C.c_uint64, C.c_int, C.POINTER(RptKdTree)]),
     ("rptgpu_kdtree_free", None, [C.POINTER(RptKdTree)]),
     ("rptgpu_buffer_create", C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     ("rptgpu_buffer_destroy", None, [_VP]),

@@ -675,15 +675,26 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     std::fprintf(stderr, "scene_create %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tc0).count());
     tc0 = t;
   };
+  // Trees of at least RPTGPU_DEVICE_BUILD_MIN primitives (default 32768; 0 = never) are built on the device when there
+  // is one — the same tree, an order of magnitude sooner for large meshes (kdbuild.hip); everything else of the
+  // flattening, and every validation, is host work.
+  rpthost::BuildOptions bopt;
+  {
+    int nd = 0;
+    bopt.device_build_min = 32768;
+    if (const char* e = std::getenv("RPTGPU_DEVICE_BUILD_MIN")) bopt.device_build_min = (size_t)std::max(0ll, std::atoll(e));
+    if (bopt.device_build_min && hipGetDeviceCount(&nd) == hipSuccess && device >= 0 && device < nd) bopt.device = device;
+    else (void)hipGetLastError();
+  }
   try {
-    rc = rpthost::flatten_scene(*scene, fs, err); // validates shapes before touching the GPU
+    rc = rpthost::flatten_scene(*scene, fs, err, &bopt); // validates shapes
   } catch (const std::bad_alloc&) {
     return fail(nullptr, RPTGPU_E_OUT_OF_MEMORY, "host allocation failed");
   } catch (...) {
     return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "unexpected exception while flattening");
   }
   if (rc != RPTGPU_OK) return fail(nullptr, rc, err);
-  lap("flatten + kd build");
+  lap(fs.trees_built_on_device ? "flatten + kd build (device)" : "flatten + kd build");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, RPTGPU_E_NO_DEVICE, "no HIP device is visible (hipGetDeviceCount); there is no CPU fallback");
@@ -1042,6 +1053,32 @@ int rptgpu_eval_math(rptgpu_scene* h, int fn, uint64_t n, const double* x, const
   return rc;
 }
 
+// KdBuild -> the malloc'ed arrays of RptKdTree
+static int kdtree_export(const rpthost::KdBuild& kb, RptKdTree* out) {
+  size_t nn = kb.nodes.size(), nr = kb.refs.size();
+  out->split = (double*)std::malloc(std::max<size_t>(nn, 1) * sizeof(double));
+  out->info = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
+  out->a = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
+  out->b = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
+  out->refs = (uint32_t*)std::malloc(std::max<size_t>(nr, 1) * sizeof(uint32_t));
+  if (!out->split || !out->info || !out->a || !out->b || !out->refs) {
+    rptgpu_kdtree_free(out);
+    return RPTGPU_E_OUT_OF_MEMORY;
+  }
+  for (size_t i = 0; i < nn; i++) {
+    out->split[i] = kb.nodes[i].split;
+    out->info[i] = kb.nodes[i].ib & 3u;
+    out->a[i] = kb.nodes[i].a;
+    out->b[i] = kb.nodes[i].ib >> 2;
+  }
+  std::memcpy(out->refs, kb.refs.data(), nr * sizeof(uint32_t));
+  out->num_nodes = nn;
+  out->num_refs = nr;
+  out->max_depth = kb.max_depth;
+  out->regular = kb.regular ? 1u : 0u;
+  return RPTGPU_OK;
+}
+
 int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out) {
   if (!out || (n && !boxes)) return RPTGPU_E_INVALID_ARGUMENT;
   std::memset(out, 0, sizeof *out);
@@ -1054,31 +1091,34 @@ int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out) {
       }
     rpthost::KdBuild kb;
     rpthost::kd_build(b, kb);
-    size_t nn = kb.nodes.size(), nr = kb.refs.size();
-    out->split = (double*)std::malloc(std::max<size_t>(nn, 1) * sizeof(double));
-    out->info = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
-    out->a = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
-    out->b = (uint32_t*)std::malloc(std::max<size_t>(nn, 1) * sizeof(uint32_t));
-    out->refs = (uint32_t*)std::malloc(std::max<size_t>(nr, 1) * sizeof(uint32_t));
-    if (!out->split || !out->info || !out->a || !out->b || !out->refs) {
-      rptgpu_kdtree_free(out);
-      return RPTGPU_E_OUT_OF_MEMORY;
-    }
-    for (size_t i = 0; i < nn; i++) {
-      out->split[i] = kb.nodes[i].split;
-      out->info[i] = kb.nodes[i].ib & 3u;
-      out->a[i] = kb.nodes[i].a;
-      out->b[i] = kb.nodes[i].ib >> 2;
-    }
-    std::memcpy(out->refs, kb.refs.data(), nr * sizeof(uint32_t));
-    out->num_nodes = nn;
-    out->num_refs = nr;
-    out->max_depth = kb.max_depth;
-    out->regular = kb.regular ? 1u : 0u;
+    return kdtree_export(kb, out);
   } catch (...) {
     return RPTGPU_E_OUT_OF_MEMORY;
   }
-  return RPTGPU_OK;
+}
+
+int rptgpu_kdtree_build_device(const double* boxes, uint64_t n, int device, RptKdTree* out) {
+  if (!out || (n && !boxes)) return RPTGPU_E_INVALID_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+    return fail(nullptr, RPTGPU_E_NO_DEVICE, "no HIP device is visible (hipGetDeviceCount); there is no CPU fallback");
+  if (device < 0 || device >= nd) return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "device index out of range");
+  try {
+    std::vector<rpthost::Box> b(n);
+    for (uint64_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        b[i].lo[k] = boxes[6 * i + k];
+        b[i].hi[k] = boxes[6 * i + 3 + k];
+      }
+    rpthost::KdBuild kb;
+    std::string why;
+    if (!rpthost::kd_build_device(b, kb, device, why))
+      return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "the device kd build does not take this input: " + why);
+    return kdtree_export(kb, out);
+  } catch (...) {
+    return RPTGPU_E_OUT_OF_MEMORY;
+  }
 }
 
 void rptgpu_kdtree_free(RptKdTree* t) {

@@ -358,10 +358,17 @@ struct Flattener {
   FlatScene& fs;
   std::string& err;
   std::map<std::pair<const void*, uint64_t>, int> mesh_cache; // shared meshes (Arc<Mesh>)
+  const BuildOptions* build = nullptr;
 
   int add_tree(const std::vector<Box>& boxes, uint32_t prim_base) {
     KdBuild kb;
-    kd_build(boxes, kb);
+    bool on_device = false;
+    if (build && build->device >= 0 && build->device_build_min && boxes.size() >= build->device_build_min) {
+      std::string why; // (a refusal is not an error: the host builder makes the same tree)
+      on_device = kd_build_device(boxes, kb, build->device, why);
+    }
+    if (on_device) fs.trees_built_on_device++;
+    else kd_build(boxes, kb);
     if (kb.max_depth > (uint32_t)rptdev::KD_MAX_STACK) {
       err = "kd-tree depth " + std::to_string(kb.max_depth) + " exceeds the device stack (" +
             std::to_string(rptdev::KD_MAX_STACK) + ")";
@@ -530,12 +537,12 @@ struct Flattener {
 
 } // namespace
 
-int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err) {
+int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const BuildOptions* build) {
   if ((sc.num_objects && !sc.objects) || (sc.num_lights && !sc.lights)) {
     err = "null objects/lights";
     return RPTGPU_E_INVALID_ARGUMENT;
   }
-  Flattener fl{fs, err, {}, {}};
+  Flattener fl{fs, err, {}, build, {}};
   fs.num_objects = (int32_t)sc.num_objects;
   fs.insts.resize(sc.num_objects);
   for (uint64_t i = 0; i < sc.num_objects; i++) {

@@ -25,6 +25,17 @@ struct KdBuild {
 // for any thread count (host_scene.cpp, splice)
 void kd_build(const std::vector<Box>& boxes, KdBuild& out, int threads = 0);
 
+// The same tree, node for node, built on HIP device `device` (kdbuild.hip: events sorted once per axis, then one round
+// of scans and stable scatters per tree level).  Returns false — `why` says why — when it cannot be used (fewer than 16
+// primitives, non-finite boxes, a HIP error, a tree deeper than the device stack): the caller builds on the host then.
+bool kd_build_device(const std::vector<Box>& boxes, KdBuild& out, int device, std::string& why);
+
+// scene hand-off options: trees of at least device_build_min primitives are built on the device (0: never)
+struct BuildOptions {
+  int device = -1;
+  size_t device_build_min = 0;
+};
+
 struct FlatScene {
   std::vector<rptdev::Inst> insts;
   std::vector<rptdev::Tree> trees;
@@ -44,11 +55,12 @@ struct FlatScene {
   int32_t num_objects = 0;
   int32_t num_shadow_lights = 0;
   uint32_t max_tree_depth = 0;
+  uint32_t trees_built_on_device = 0; // how many of the trees kd_build_device made (diagnostics)
   bool nested_mesh = false; // some KdTree<Box<dyn Bounded>> child is a Mesh, a MonomialSurface or another group:
                             // the scene needs the extended kernel builds
 };
 
 // returns RPTGPU_OK or an error code; `err` explains
-int flatten_scene(const RptScene& scene, FlatScene& out, std::string& err);
+int flatten_scene(const RptScene& scene, FlatScene& out, std::string& err, const BuildOptions* build = nullptr);
 
 } // namespace rpthost

@@ -127,14 +127,17 @@ class GpuScene:
         _abi.check(self.lib.rptgpu_reset_stats(self.handle), self.handle)
 
 
-def kdtree_build(boxes, lib=None, prefix="rptgpu"):
-    """KdTree::new over (n, 6) boxes through the C ABI -> dict of numpy arrays."""
+def kdtree_build(boxes, lib=None, prefix="rptgpu", device=None):
+    """KdTree::new over (n, 6) boxes through the C ABI -> dict of numpy arrays.  device: build on that HIP device
+    (rptgpu_kdtree_build_device) instead of the host."""
     lib = lib or _abi.load_library()
     b = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
     t = _abi.RptKdTree()
-    build = getattr(lib, prefix + "_kdtree_build")
     free = getattr(lib, prefix + "_kdtree_free")
-    code = build(b.ctypes.data_as(C.POINTER(C.c_double)), len(b), C.byref(t))
+    if device is None:
+        code = getattr(lib, prefix + "_kdtree_build")(b.ctypes.data_as(C.POINTER(C.c_double)), len(b), C.byref(t))
+    else:
+        code = lib.rptgpu_kdtree_build_device(b.ctypes.data_as(C.POINTER(C.c_double)), len(b), int(device), C.byref(t))
     if code != 0:
         raise _abi.RptGpuError(code, "kdtree_build")
     n, r = t.num_nodes, t.num_refs

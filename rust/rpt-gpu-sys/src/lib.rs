@@ -228,6 +228,7 @@ pub mod ffi {
         pub fn rptgpu_render_batch_reduce(h: *mut rptgpu_scene, camera: *const RptCamera, params: *const RptRenderParams, root: c_int, out_rgb32: *mut f32) -> c_int;
         pub fn rptgpu_closest_hit(h: *mut rptgpu_scene, n: u64, origins: *const f64, dirs: *const f64, precision_mode: u32, out_t: *mut f64, out_normal: *mut f64, out_object: *mut i32) -> c_int;
         pub fn rptgpu_kdtree_build(boxes: *const f64, n: u64, out: *mut RptKdTree) -> c_int;
+        pub fn rptgpu_kdtree_build_device(boxes: *const f64, n: u64, device: c_int, out: *mut RptKdTree) -> c_int;
         pub fn rptgpu_kdtree_free(tree: *mut RptKdTree);
         pub fn rptgpu_eval_math(h: *mut rptgpu_scene, func: c_int, n: u64, x: *const f64, y: *const f64, out: *mut f64) -> c_int;
         pub fn rptgpu_buffer_create(h: *mut rptgpu_scene, width: u32, height: u32, filter_radius: u32, out: *mut *mut rptgpu_buffer) -> c_int;
