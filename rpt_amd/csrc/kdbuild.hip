@@ -46,23 +46,6 @@ struct HipErr {
     if (_e != hipSuccess) throw HipErr{_e, #expr, __LINE__};  \
   } while (0)
 
-template <class T> struct Dev {
-  T* p = nullptr;
-  size_t n = 0;
-  Dev() = default;
-  Dev(const Dev&) = delete;
-  Dev& operator=(const Dev&) = delete;
-  ~Dev() { if (p) (void)hipFree(p); }
-  void need(size_t count) { // grow-only, contents NOT kept; half as much again so that growing levels do not realloc each time
-    if (count <= n && p) return;
-    if (p) (void)hipFree(p);
-    p = nullptr; n = 0;
-    count = std::max<size_t>(count + count / 2, 16);
-    KD_TRY(hipMalloc((void**)&p, count * sizeof(T)));
-    n = count;
-  }
-};
-
 constexpr double SCORE_THRESHOLD = 0.85; // kdtree.rs:6
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
@@ -170,6 +153,7 @@ __global__ void k_decide(const Task* __restrict__ tasks, uint32_t nt, Decision* 
                          uint32_t* __restrict__ is_split, uint32_t* __restrict__ leaf_count,
                          uint32_t* __restrict__ child_count /* [2 nt] */, uint32_t* __restrict__ irregular) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == nt) { is_split[nt] = 0u; leaf_count[nt] = 0u; child_count[2 * nt] = 0u; } // the scans' extra element: totals
   if (t >= nt) return;
   const Task tk = tasks[t];
   Decision d = dec[t];
@@ -328,25 +312,195 @@ __global__ void k_ev_task0(uint32_t n2, uint32_t* __restrict__ ev_task) {
   if (e < n2) ev_task[e] = 0u;
 }
 
+__global__ void k_totals(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out) {
+  out[0] = *a; out[1] = *b; out[2] = *c;
+}
+
 inline dim3 grid(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// one device allocation per build, carved up front: hipMalloc / hipFree cost more than whole levels of this build
+struct Arena {
+  char* base = nullptr;
+  size_t size = 0, off = 0;
+  ~Arena() { if (base) (void)hipFree(base); }
+  template <class T> T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(base + off);
+    off += std::max<size_t>(count, 1) * sizeof(T);
+    return p;
+  }
+};
+
+enum class Attempt { done, grow, failed };
+
+// One attempt with room for `cap` primitive instances per level.  Attempt::grow: some level needed more.
+Attempt build_once(const std::vector<double>& soa, size_t n, const Box& root, size_t cap, hipStream_t st, uint32_t* pinned,
+                   KdBuild& out, std::string& why) {
+  const size_t task_cap = cap / 2 + 64, node_cap = cap + 64, leaf_cap = 2 * cap + 64;
+  size_t t_sort = 0, t_s32 = 0, t_s64 = 0;
+  KD_TRY(rocprim::radix_sort_pairs(nullptr, t_sort, (double*)nullptr, (double*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 2 * n, 0, 64, st));
+  KD_TRY(rocprim::exclusive_scan(nullptr, t_s32, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 2 * task_cap + 1, rocprim::plus<uint32_t>(), st));
+  KD_TRY(rocprim::exclusive_scan(nullptr, t_s64, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, 2 * cap,
+                                 rocprim::plus<unsigned long long>(), st));
+  const size_t tmp_bytes = std::max(t_sort, std::max(t_s32, t_s64)) + 256;
+  // bytes: boxes 48 n; per instance slot: inst + task_of (2 halves) 16, events (2 halves x 3 axes x 2) 48, their task
+  // (2 halves x 2) 16, positions 8, flags + scanned flags (2 x 2 x 8) 32; leaves 8; nodes 16; tasks / decisions ~150 per task
+  const size_t bytes = 48 * n + cap * (16 + 48 + 16 + 8 + 32) + leaf_cap * 4 + node_cap * sizeof(BfsNode) +
+                       task_cap * (2 * sizeof(Task) + sizeof(Decision) + 8 * 4) + 24 * n + tmp_bytes + (1u << 20);
+  Arena ar;
+  KD_TRY(hipMalloc((void**)&ar.base, bytes));
+  ar.size = bytes;
+  double* d_soa = ar.take<double>(6 * n);
+  uint32_t *inst[2], *task_of[2], *ev[2][3], *ev_task[2];
+  for (int h = 0; h < 2; h++) {
+    inst[h] = ar.take<uint32_t>(cap); task_of[h] = ar.take<uint32_t>(cap);
+    for (int k = 0; k < 3; k++) ev[h][k] = ar.take<uint32_t>(2 * cap);
+    ev_task[h] = ar.take<uint32_t>(2 * cap); // (an event's node does not depend on the axis: segments coincide)
+  }
+  uint32_t *pos_l = ar.take<uint32_t>(cap), *pos_r = ar.take<uint32_t>(cap), *leaves = ar.take<uint32_t>(leaf_cap);
+  unsigned long long *fl = ar.take<unsigned long long>(2 * cap), *sfl = ar.take<unsigned long long>(2 * cap);
+  Task* tasks[2] = {ar.take<Task>(task_cap), ar.take<Task>(task_cap)};
+  Decision* dec = ar.take<Decision>(task_cap);
+  uint32_t *is_split = ar.take<uint32_t>(task_cap + 1), *split_rank = ar.take<uint32_t>(task_cap + 1);
+  uint32_t *leaf_count = ar.take<uint32_t>(task_cap + 1), *leaf_start = ar.take<uint32_t>(task_cap + 1);
+  uint32_t *child_count = ar.take<uint32_t>(2 * task_cap + 1), *child_start = ar.take<uint32_t>(2 * task_cap + 1);
+  uint32_t *flag = ar.take<uint32_t>(4), *d_totals = ar.take<uint32_t>(4);
+  BfsNode* d_nodes = ar.take<BfsNode>(node_cap);
+  double *keys_in = ar.take<double>(2 * n), *keys_out = ar.take<double>(2 * n);
+  uint32_t* vals_in = ar.take<uint32_t>(2 * n);
+  void* tmp = ar.take<char>(tmp_bytes);
+  if (ar.off > ar.size) { why = "internal: arena too small"; return Attempt::failed; }
+
+  KD_TRY(hipMemcpyAsync(d_soa, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  Boxes bx;
+  for (int k = 0; k < 3; k++) { bx.lo[k] = d_soa + (size_t)k * n; bx.hi[k] = d_soa + (size_t)(3 + k) * n; }
+  KD_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+
+  // level 0: every primitive once, events sorted per axis
+  hipLaunchKernelGGL(k_iota, grid(n), dim3(256), 0, st, (uint32_t)n, inst[0], task_of[0]);
+  hipLaunchKernelGGL(k_ev_task0, grid(2 * n), dim3(256), 0, st, (uint32_t)(2 * n), ev_task[0]);
+  for (int k = 0; k < 3; k++) {
+    hipLaunchKernelGGL(k_make_events, grid(n), dim3(256), 0, st, bx, k, (uint32_t)n, keys_in, vals_in);
+    size_t b2 = tmp_bytes;
+    KD_TRY(rocprim::radix_sort_pairs(tmp, b2, keys_in, keys_out, vals_in, ev[0][k], 2 * n, 0, 64, st));
+  }
+  Task t0{};
+  t0.start = 0; t0.count = (uint32_t)n;
+  for (int k = 0; k < 3; k++) { t0.clo[k] = root.lo[k]; t0.chi[k] = root.hi[k]; }
+  KD_TRY(hipMemcpyAsync(tasks[0], &t0, sizeof t0, hipMemcpyHostToDevice, st));
+
+  struct Level { uint32_t first_node, nt; };
+  std::vector<Level> levels;
+  size_t nt = 1, ninst = n, nodes_total = 0, leaf_total = 0;
+  int cur = 0;
+  auto scan_u32 = [&](uint32_t* in, uint32_t* outp, size_t count) {
+    size_t b2 = tmp_bytes;
+    KD_TRY(rocprim::exclusive_scan(tmp, b2, in, outp, 0u, count, rocprim::plus<uint32_t>(), st));
+  };
+  auto scan_u64 = [&](unsigned long long* in, unsigned long long* outp, size_t count) {
+    size_t b2 = tmp_bytes;
+    KD_TRY(rocprim::exclusive_scan(tmp, b2, in, outp, 0ull, count, rocprim::plus<unsigned long long>(), st));
+  };
+  for (uint32_t depth = 0;; depth++) {
+    if (depth > (uint32_t)rptdev::KD_MAX_STACK + 1) { // the host builder will say so properly (RPTGPU_E_TREE_TOO_DEEP)
+      why = "tree deeper than the device traversal stack";
+      return Attempt::failed;
+    }
+    if (nodes_total + nt > node_cap || leaf_total + ninst > leaf_cap) return Attempt::grow;
+    const int nxt = cur ^ 1;
+    hipLaunchKernelGGL(k_medians, grid(nt), dim3(256), 0, st, bx, tasks[cur], (uint32_t)nt, inst[cur], ev[cur][0], ev[cur][1],
+                       ev[cur][2], dec);
+    hipLaunchKernelGGL(k_scores, grid(ninst), dim3(256), 0, st, bx, tasks[cur], inst[cur], task_of[cur], (uint32_t)ninst, dec);
+    hipLaunchKernelGGL(k_decide, grid(nt + 1), dim3(256), 0, st, tasks[cur], (uint32_t)nt, dec, is_split, leaf_count, child_count, flag);
+    // (k_decide also zeroes the element past the end of each array: the exclusive scan's last entry is the total)
+    scan_u32(is_split, split_rank, nt + 1);
+    scan_u32(leaf_count, leaf_start, nt + 1);
+    scan_u32(child_count, child_start, 2 * nt + 1);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, st, split_rank + nt, leaf_start + nt, child_start + 2 * nt, d_totals);
+    KD_TRY(hipMemcpyAsync(pinned, d_totals, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    KD_TRY(hipStreamSynchronize(st));
+    const size_t n_split = pinned[0], n_leaf_inst = pinned[1], n_next = pinned[2];
+    if (n_next > cap || 2 * n_split > task_cap) return Attempt::grow;
+    hipLaunchKernelGGL(k_emit, grid(nt), dim3(256), 0, st, tasks[cur], (uint32_t)nt, dec, split_rank, child_start, leaf_start,
+                       (uint32_t)leaf_total, d_nodes + nodes_total, tasks[nxt]);
+    hipLaunchKernelGGL(k_flags, grid(ninst), dim3(256), 0, st, bx, dec, inst[cur], task_of[cur], (uint32_t)ninst, fl);
+    scan_u64(fl, sfl, ninst);
+    hipLaunchKernelGGL(k_scatter_inst, grid(ninst), dim3(256), 0, st, tasks[cur], dec, inst[cur], task_of[cur], (uint32_t)ninst,
+                       fl, sfl, child_start, leaf_start, (uint32_t)leaf_total, inst[nxt], task_of[nxt], pos_l, pos_r, leaves);
+    if (n_split) {
+      for (int k = 0; k < 3; k++) {
+        hipLaunchKernelGGL(k_ev_flags, grid(2 * ninst), dim3(256), 0, st, tasks[cur], task_of[cur], ev[cur][k],
+                           (uint32_t)(2 * ninst), pos_l, pos_r, ev_task[cur], fl);
+        scan_u64(fl, sfl, 2 * ninst);
+        hipLaunchKernelGGL(k_ev_scatter, grid(2 * ninst), dim3(256), 0, st, tasks[cur], tasks[nxt], dec, ev[cur][k],
+                           (uint32_t)(2 * ninst), pos_l, pos_r, ev_task[cur], fl, sfl, ev[nxt][k], ev_task[nxt]);
+      }
+    }
+    levels.push_back({(uint32_t)nodes_total, (uint32_t)nt});
+    nodes_total += nt;
+    leaf_total += n_leaf_inst;
+    if (!n_split) break;
+    nt = 2 * n_split;
+    ninst = n_next;
+    cur = nxt;
+  }
+  KD_TRY(hipGetLastError());
+  // ---- to the host: breadth-first nodes, leaf buffer; renumber depth-first as construct() numbers them
+  std::vector<BfsNode> bfs(nodes_total);
+  std::vector<uint32_t> leaf_host(std::max<size_t>(leaf_total, 1));
+  KD_TRY(hipMemcpyAsync(bfs.data(), d_nodes, nodes_total * sizeof(BfsNode), hipMemcpyDeviceToHost, st));
+  if (leaf_total) KD_TRY(hipMemcpyAsync(leaf_host.data(), leaves, leaf_total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  KD_TRY(hipMemcpyAsync(pinned, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  KD_TRY(hipStreamSynchronize(st));
+  const uint32_t irregular = pinned[0];
+
+  out.nodes.clear(); out.refs.clear();
+  out.nodes.reserve(nodes_total); out.refs.reserve(leaf_total);
+  out.max_depth = (uint32_t)levels.size() - 1u;
+  out.regular = irregular == 0;
+  out.nodes.push_back({});
+  struct Item { uint32_t level, index, dfs; };
+  std::vector<Item> stack{{0u, 0u, 0u}};
+  while (!stack.empty()) {
+    const Item it = stack.back();
+    stack.pop_back();
+    const BfsNode& b = bfs[levels[it.level].first_node + it.index];
+    if ((b.info & 3u) == 3u) {
+      const uint32_t cnt = b.info >> 2;
+      rptdev::KdNode& nd = out.nodes[it.dfs];
+      nd.split = 0.0; nd.a = (uint32_t)out.refs.size(); nd.ib = 3u | (cnt << 2);
+      out.refs.insert(out.refs.end(), leaf_host.begin() + b.a, leaf_host.begin() + b.a + cnt);
+    } else {
+      const uint32_t l = (uint32_t)out.nodes.size();
+      out.nodes.push_back({});
+      out.nodes.push_back({});
+      rptdev::KdNode& nd = out.nodes[it.dfs];
+      nd.split = b.split; nd.a = l; nd.ib = b.info;
+      // construct() builds the whole left subtree before the right one: the right child waits on the stack
+      stack.push_back({it.level + 1u, b.a + 1u, l + 1u});
+      stack.push_back({it.level + 1u, b.a, l});
+    }
+  }
+  return Attempt::done;
+}
 
 } // namespace
 
 // returns false (with `why`) when the device build cannot be used — the caller builds on the host then
 bool kd_build_device(const std::vector<Box>& boxes, KdBuild& out, int device, std::string& why) {
   const size_t n = boxes.size();
-  if (n < 16 || n >= (1ull << 30)) { why = "primitive count outside the device builder's range"; return false; }
+  if (n < 16 || n >= (1ull << 28)) { why = "primitive count outside the device builder's range"; return false; }
   for (const Box& b : boxes)
     for (int k = 0; k < 3; k++)
       if (!std::isfinite(b.lo[k]) || !std::isfinite(b.hi[k])) { why = "non-finite box"; return false; }
+  hipStream_t st = nullptr;
+  uint32_t* pinned = nullptr;
+  bool ok = false;
   try {
     KD_TRY(hipSetDevice(device));
-    hipStream_t st = nullptr;
     KD_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } guard{st};
-
-    // boxes, structure of arrays
-    std::vector<double> soa(6 * n);
+    KD_TRY(hipHostMalloc((void**)&pinned, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    std::vector<double> soa(6 * n); // boxes, structure of arrays
     Box root;
     for (int k = 0; k < 3; k++) { root.lo[k] = INFINITY; root.hi[k] = -INFINITY; }
     for (size_t i = 0; i < n; i++)
@@ -356,181 +510,23 @@ bool kd_build_device(const std::vector<Box>& boxes, KdBuild& out, int device, st
         root.lo[k] = std::fmin(root.lo[k], boxes[i].lo[k]);
         root.hi[k] = std::fmax(root.hi[k], boxes[i].hi[k]);
       }
-    Dev<double> d_soa;
-    d_soa.need(6 * n);
-    KD_TRY(hipMemcpyAsync(d_soa.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    Boxes bx;
-    for (int k = 0; k < 3; k++) { bx.lo[k] = d_soa.p + (size_t)k * n; bx.hi[k] = d_soa.p + (size_t)(3 + k) * n; }
-
-    // level buffers, double-buffered, sized per level (a level holds more instances than the one above: straddlers)
-    Dev<uint32_t> inst[2], task_of[2], ev[2][3], ev_task[2][3], pos_l, pos_r, leaves;
-    Dev<unsigned long long> fl, sfl;
-    Dev<Task> tasks[2];
-    Dev<Decision> dec;
-    Dev<uint32_t> is_split, split_rank, leaf_count, leaf_start, child_count, child_start, flag;
-    Dev<BfsNode> d_nodes;
-    Dev<uint8_t> tmp;
-    auto size_level = [&](int which, size_t c) {
-      inst[which].need(c); task_of[which].need(c);
-      for (int k = 0; k < 3; k++) { ev[which][k].need(2 * c); ev_task[which][k].need(2 * c); }
-    };
-    size_level(0, n);
-    flag.need(1);
-    KD_TRY(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), st));
-
-    // level 0: every primitive once, events sorted per axis
-    {
-      Dev<double> keys_in, keys_out;
-      Dev<uint32_t> vals_in;
-      keys_in.need(2 * n); keys_out.need(2 * n); vals_in.need(2 * n);
-      size_t bytes = 0;
-      KD_TRY(rocprim::radix_sort_pairs(nullptr, bytes, keys_in.p, keys_out.p, vals_in.p, ev[0][0].p, 2 * n, 0, 64, st));
-      tmp.need(bytes);
-      hipLaunchKernelGGL(k_iota, grid(n), dim3(256), 0, st, (uint32_t)n, inst[0].p, task_of[0].p);
-      for (int k = 0; k < 3; k++) {
-        hipLaunchKernelGGL(k_make_events, grid(n), dim3(256), 0, st, bx, k, (uint32_t)n, keys_in.p, vals_in.p);
-        size_t b2 = tmp.n;
-        KD_TRY(rocprim::radix_sort_pairs(tmp.p, b2, keys_in.p, keys_out.p, vals_in.p, ev[0][k].p, 2 * n, 0, 64, st));
-        hipLaunchKernelGGL(k_ev_task0, grid(2 * n), dim3(256), 0, st, (uint32_t)(2 * n), ev_task[0][k].p);
-      }
-      KD_TRY(hipStreamSynchronize(st)); // keys_* die with this block
+    // a level holds more instances than primitives (straddlers go to both children): room for 6 n, doubled when a
+    // level needs more (the reference rule duplicates ~4.5x on meshes)
+    size_t cap = std::max<size_t>(6 * n, 4096);
+    for (int attempt = 0; attempt < 6; attempt++, cap *= 2) {
+      Attempt r = build_once(soa, n, root, cap, st, pinned, out, why);
+      if (r == Attempt::done) { ok = true; break; }
+      if (r == Attempt::failed) break;
+      why = "the tree duplicates its primitives more than 190 times";
     }
-    Task t0{};
-    t0.start = 0; t0.count = (uint32_t)n;
-    for (int k = 0; k < 3; k++) { t0.clo[k] = root.lo[k]; t0.chi[k] = root.hi[k]; }
-    tasks[0].need(1);
-    KD_TRY(hipMemcpyAsync(tasks[0].p, &t0, sizeof t0, hipMemcpyHostToDevice, st));
-
-    struct Level { uint32_t first_node, nt; };
-    std::vector<Level> levels;
-    size_t nt = 1, ninst = n, nodes_total = 0, leaf_total = 0;
-    int cur = 0;
-    auto scan_u32 = [&](uint32_t* in, uint32_t* outp, size_t count) {
-      size_t bytes = 0;
-      KD_TRY(rocprim::exclusive_scan(nullptr, bytes, in, outp, 0u, count, rocprim::plus<uint32_t>(), st));
-      tmp.need(bytes);
-      bytes = tmp.n;
-      KD_TRY(rocprim::exclusive_scan(tmp.p, bytes, in, outp, 0u, count, rocprim::plus<uint32_t>(), st));
-    };
-    auto scan_u64 = [&](unsigned long long* in, unsigned long long* outp, size_t count) {
-      size_t bytes = 0;
-      KD_TRY(rocprim::exclusive_scan(nullptr, bytes, in, outp, 0ull, count, rocprim::plus<unsigned long long>(), st));
-      tmp.need(bytes);
-      bytes = tmp.n;
-      KD_TRY(rocprim::exclusive_scan(tmp.p, bytes, in, outp, 0ull, count, rocprim::plus<unsigned long long>(), st));
-    };
-    uint32_t depth = 0;
-    for (;; depth++) {
-      if (depth > (uint32_t)rptdev::KD_MAX_STACK + 1) { // the host builder will say so properly (RPTGPU_E_TREE_TOO_DEEP)
-        why = "tree deeper than the device traversal stack";
-        return false;
-      }
-      const int nxt = cur ^ 1;
-      dec.need(nt); is_split.need(nt + 1); split_rank.need(nt + 1); leaf_count.need(nt + 1); leaf_start.need(nt + 1);
-      child_count.need(2 * nt + 1); child_start.need(2 * nt + 1);
-      if (nodes_total + nt > d_nodes.n) { // grow, keeping what is there
-        Dev<BfsNode> bigger;
-        bigger.need(2 * (nodes_total + nt));
-        if (nodes_total) KD_TRY(hipMemcpyAsync(bigger.p, d_nodes.p, nodes_total * sizeof(BfsNode), hipMemcpyDeviceToDevice, st));
-        KD_TRY(hipStreamSynchronize(st));
-        std::swap(bigger.p, d_nodes.p); std::swap(bigger.n, d_nodes.n);
-      }
-      if (leaf_total + ninst > leaves.n) {
-        Dev<uint32_t> bigger;
-        bigger.need(2 * (leaf_total + ninst));
-        if (leaf_total) KD_TRY(hipMemcpyAsync(bigger.p, leaves.p, leaf_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        KD_TRY(hipStreamSynchronize(st));
-        std::swap(bigger.p, leaves.p); std::swap(bigger.n, leaves.n);
-      }
-      hipLaunchKernelGGL(k_medians, grid(nt), dim3(256), 0, st, bx, tasks[cur].p, (uint32_t)nt, inst[cur].p, ev[cur][0].p,
-                         ev[cur][1].p, ev[cur][2].p, dec.p);
-      hipLaunchKernelGGL(k_scores, grid(ninst), dim3(256), 0, st, bx, tasks[cur].p, inst[cur].p, task_of[cur].p,
-                         (uint32_t)ninst, dec.p);
-      hipLaunchKernelGGL(k_decide, grid(nt), dim3(256), 0, st, tasks[cur].p, (uint32_t)nt, dec.p, is_split.p, leaf_count.p,
-                         child_count.p, flag.p);
-      // one extra element: the exclusive scan's last entry is the total
-      KD_TRY(hipMemsetAsync(is_split.p + nt, 0, sizeof(uint32_t), st));
-      KD_TRY(hipMemsetAsync(leaf_count.p + nt, 0, sizeof(uint32_t), st));
-      KD_TRY(hipMemsetAsync(child_count.p + 2 * nt, 0, sizeof(uint32_t), st));
-      scan_u32(is_split.p, split_rank.p, nt + 1);
-      scan_u32(leaf_count.p, leaf_start.p, nt + 1);
-      scan_u32(child_count.p, child_start.p, 2 * nt + 1);
-      uint32_t totals[3];
-      KD_TRY(hipMemcpyAsync(&totals[0], split_rank.p + nt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      KD_TRY(hipMemcpyAsync(&totals[1], leaf_start.p + nt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      KD_TRY(hipMemcpyAsync(&totals[2], child_start.p + 2 * nt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      KD_TRY(hipStreamSynchronize(st));
-      const size_t n_split = totals[0], n_leaf_inst = totals[1], n_next = totals[2];
-      size_level(nxt, std::max<size_t>(n_next, 1)); // (the other half of the double buffer: about to be overwritten)
-      pos_l.need(ninst); pos_r.need(ninst); fl.need(2 * ninst); sfl.need(2 * ninst);
-      tasks[nxt].need(std::max<size_t>(2 * n_split, 1));
-      hipLaunchKernelGGL(k_emit, grid(nt), dim3(256), 0, st, tasks[cur].p, (uint32_t)nt, dec.p, split_rank.p, child_start.p,
-                         leaf_start.p, (uint32_t)leaf_total, d_nodes.p + nodes_total, tasks[nxt].p);
-      hipLaunchKernelGGL(k_flags, grid(ninst), dim3(256), 0, st, bx, dec.p, inst[cur].p, task_of[cur].p, (uint32_t)ninst, fl.p);
-      scan_u64(fl.p, sfl.p, ninst);
-      hipLaunchKernelGGL(k_scatter_inst, grid(ninst), dim3(256), 0, st, tasks[cur].p, dec.p, inst[cur].p, task_of[cur].p,
-                         (uint32_t)ninst, fl.p, sfl.p, child_start.p, leaf_start.p, (uint32_t)leaf_total, inst[nxt].p,
-                         task_of[nxt].p, pos_l.p, pos_r.p, leaves.p);
-      if (n_split) {
-        for (int k = 0; k < 3; k++) {
-          hipLaunchKernelGGL(k_ev_flags, grid(2 * ninst), dim3(256), 0, st, tasks[cur].p, task_of[cur].p, ev[cur][k].p,
-                             (uint32_t)(2 * ninst), pos_l.p, pos_r.p, ev_task[cur][k].p, fl.p);
-          scan_u64(fl.p, sfl.p, 2 * ninst);
-          hipLaunchKernelGGL(k_ev_scatter, grid(2 * ninst), dim3(256), 0, st, tasks[cur].p, tasks[nxt].p, dec.p, ev[cur][k].p,
-                             (uint32_t)(2 * ninst), pos_l.p, pos_r.p, ev_task[cur][k].p, fl.p, sfl.p, ev[nxt][k].p,
-                             ev_task[nxt][k].p);
-        }
-      }
-      levels.push_back({(uint32_t)nodes_total, (uint32_t)nt});
-      nodes_total += nt;
-      leaf_total += n_leaf_inst;
-      if (!n_split) break;
-      nt = 2 * n_split;
-      ninst = n_next;
-      cur = nxt;
-    }
-    KD_TRY(hipGetLastError());
-    // ---- to the host: breadth-first nodes, leaf buffer; renumber depth-first as construct() numbers them
-    std::vector<BfsNode> bfs(nodes_total);
-    std::vector<uint32_t> leaf_host(std::max<size_t>(leaf_total, 1));
-    uint32_t irregular = 0;
-    KD_TRY(hipMemcpyAsync(bfs.data(), d_nodes.p, nodes_total * sizeof(BfsNode), hipMemcpyDeviceToHost, st));
-    if (leaf_total) KD_TRY(hipMemcpyAsync(leaf_host.data(), leaves.p, leaf_total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    KD_TRY(hipMemcpyAsync(&irregular, flag.p, sizeof irregular, hipMemcpyDeviceToHost, st));
-    KD_TRY(hipStreamSynchronize(st));
-
-    out.nodes.clear(); out.refs.clear();
-    out.nodes.reserve(nodes_total); out.refs.reserve(leaf_total);
-    out.max_depth = (uint32_t)levels.size() - 1u;
-    out.regular = irregular == 0;
-    out.nodes.push_back({});
-    struct Item { uint32_t level, index, dfs; };
-    std::vector<Item> stack{{0u, 0u, 0u}};
-    while (!stack.empty()) {
-      const Item it = stack.back();
-      stack.pop_back();
-      const BfsNode& b = bfs[levels[it.level].first_node + it.index];
-      rptdev::KdNode& nd = out.nodes[it.dfs];
-      if ((b.info & 3u) == 3u) {
-        const uint32_t cnt = b.info >> 2;
-        nd.split = 0.0; nd.a = (uint32_t)out.refs.size(); nd.ib = 3u | (cnt << 2);
-        out.refs.insert(out.refs.end(), leaf_host.begin() + b.a, leaf_host.begin() + b.a + cnt);
-      } else {
-        const uint32_t l = (uint32_t)out.nodes.size();
-        nd.split = b.split; nd.a = l; nd.ib = b.info;
-        out.nodes.push_back({});
-        out.nodes.push_back({});
-        // construct() builds the whole left subtree before the right one: the right child waits on the stack
-        stack.push_back({it.level + 1u, b.a + 1u, l + 1u});
-        stack.push_back({it.level + 1u, b.a, l});
-      }
-    }
-    return true;
   } catch (const HipErr& e) {
     (void)hipGetLastError();
     why = std::string(e.what) + ": " + hipGetErrorString(e.e);
-    return false;
+    ok = false;
   }
+  if (pinned) (void)hipHostFree(pinned);
+  if (st) (void)hipStreamDestroy(st);
+  return ok;
 }
 
 } // namespace rpthost
