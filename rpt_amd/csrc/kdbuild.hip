@@ -343,33 +343,41 @@ Attempt build_once(const std::vector<double>& soa, size_t n, const Box& root, si
   KD_TRY(rocprim::exclusive_scan(nullptr, t_s64, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, 2 * cap,
                                  rocprim::plus<unsigned long long>(), st));
   const size_t tmp_bytes = std::max(t_sort, std::max(t_s32, t_s64)) + 256;
-  // bytes: boxes 48 n; per instance slot: inst + task_of (2 halves) 16, events (2 halves x 3 axes x 2) 48, their task
-  // (2 halves x 2) 16, positions 8, flags + scanned flags (2 x 2 x 8) 32; leaves 8; nodes 16; tasks / decisions ~150 per task
-  const size_t bytes = 48 * n + cap * (16 + 48 + 16 + 8 + 32) + leaf_cap * 4 + node_cap * sizeof(BfsNode) +
-                       task_cap * (2 * sizeof(Task) + sizeof(Decision) + 8 * 4) + 24 * n + tmp_bytes + (1u << 20);
+  // the layout is walked twice: once over a null arena to measure it, once over the allocation
+  double *d_soa = nullptr, *keys_in = nullptr, *keys_out = nullptr;
+  uint32_t *inst[2], *task_of[2], *ev[2][3], *ev_task[2], *pos_l = nullptr, *pos_r = nullptr, *leaves = nullptr;
+  unsigned long long *fl = nullptr, *sfl = nullptr;
+  Task* tasks[2];
+  Decision* dec = nullptr;
+  uint32_t *is_split = nullptr, *split_rank = nullptr, *leaf_count = nullptr, *leaf_start = nullptr, *child_count = nullptr,
+           *child_start = nullptr, *flag = nullptr, *d_totals = nullptr, *vals_in = nullptr;
+  BfsNode* d_nodes = nullptr;
+  void* tmp = nullptr;
+  auto layout = [&](Arena& ar) {
+    d_soa = ar.take<double>(6 * n);
+    for (int h = 0; h < 2; h++) {
+      inst[h] = ar.take<uint32_t>(cap); task_of[h] = ar.take<uint32_t>(cap);
+      for (int k = 0; k < 3; k++) ev[h][k] = ar.take<uint32_t>(2 * cap);
+      ev_task[h] = ar.take<uint32_t>(2 * cap); // (an event's node does not depend on the axis: the segments coincide)
+    }
+    pos_l = ar.take<uint32_t>(cap); pos_r = ar.take<uint32_t>(cap); leaves = ar.take<uint32_t>(leaf_cap);
+    fl = ar.take<unsigned long long>(2 * cap); sfl = ar.take<unsigned long long>(2 * cap);
+    tasks[0] = ar.take<Task>(task_cap); tasks[1] = ar.take<Task>(task_cap);
+    dec = ar.take<Decision>(task_cap);
+    is_split = ar.take<uint32_t>(task_cap + 1); split_rank = ar.take<uint32_t>(task_cap + 1);
+    leaf_count = ar.take<uint32_t>(task_cap + 1); leaf_start = ar.take<uint32_t>(task_cap + 1);
+    child_count = ar.take<uint32_t>(2 * task_cap + 1); child_start = ar.take<uint32_t>(2 * task_cap + 1);
+    flag = ar.take<uint32_t>(4); d_totals = ar.take<uint32_t>(4);
+    d_nodes = ar.take<BfsNode>(node_cap);
+    keys_in = ar.take<double>(2 * n); keys_out = ar.take<double>(2 * n); vals_in = ar.take<uint32_t>(2 * n);
+    tmp = ar.take<char>(tmp_bytes);
+  };
+  Arena measure;
+  layout(measure);
   Arena ar;
-  KD_TRY(hipMalloc((void**)&ar.base, bytes));
-  ar.size = bytes;
-  double* d_soa = ar.take<double>(6 * n);
-  uint32_t *inst[2], *task_of[2], *ev[2][3], *ev_task[2];
-  for (int h = 0; h < 2; h++) {
-    inst[h] = ar.take<uint32_t>(cap); task_of[h] = ar.take<uint32_t>(cap);
-    for (int k = 0; k < 3; k++) ev[h][k] = ar.take<uint32_t>(2 * cap);
-    ev_task[h] = ar.take<uint32_t>(2 * cap); // (an event's node does not depend on the axis: segments coincide)
-  }
-  uint32_t *pos_l = ar.take<uint32_t>(cap), *pos_r = ar.take<uint32_t>(cap), *leaves = ar.take<uint32_t>(leaf_cap);
-  unsigned long long *fl = ar.take<unsigned long long>(2 * cap), *sfl = ar.take<unsigned long long>(2 * cap);
-  Task* tasks[2] = {ar.take<Task>(task_cap), ar.take<Task>(task_cap)};
-  Decision* dec = ar.take<Decision>(task_cap);
-  uint32_t *is_split = ar.take<uint32_t>(task_cap + 1), *split_rank = ar.take<uint32_t>(task_cap + 1);
-  uint32_t *leaf_count = ar.take<uint32_t>(task_cap + 1), *leaf_start = ar.take<uint32_t>(task_cap + 1);
-  uint32_t *child_count = ar.take<uint32_t>(2 * task_cap + 1), *child_start = ar.take<uint32_t>(2 * task_cap + 1);
-  uint32_t *flag = ar.take<uint32_t>(4), *d_totals = ar.take<uint32_t>(4);
-  BfsNode* d_nodes = ar.take<BfsNode>(node_cap);
-  double *keys_in = ar.take<double>(2 * n), *keys_out = ar.take<double>(2 * n);
-  uint32_t* vals_in = ar.take<uint32_t>(2 * n);
-  void* tmp = ar.take<char>(tmp_bytes);
-  if (ar.off > ar.size) { why = "internal: arena too small"; return Attempt::failed; }
+  ar.size = measure.off + 256;
+  KD_TRY(hipMalloc((void**)&ar.base, ar.size));
+  layout(ar);
 
   KD_TRY(hipMemcpyAsync(d_soa, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, st));
   Boxes bx;

@@ -139,7 +139,8 @@ def kdtree_build(boxes, lib=None, prefix="rptgpu", device=None):
     else:
         code = lib.rptgpu_kdtree_build_device(b.ctypes.data_as(C.POINTER(C.c_double)), len(b), int(device), C.byref(t))
     if code != 0:
-        raise _abi.RptGpuError(code, "kdtree_build")
+        detail = lib.rptgpu_last_error_detail(None) if prefix == "rptgpu" else b""
+        raise _abi.RptGpuError(code, "kdtree_build: " + (detail.decode() if detail else ""))
     n, r = t.num_nodes, t.num_refs
     out = {
         "split": np.ctypeslib.as_array(t.split, (n,)).copy(),
