@@ -25,6 +25,43 @@ namespace rpthost {
 
 namespace {
 
+// CPUs this process may actually run on: the affinity mask and the cgroup v2 quota, not the machine's core count
+// (a GPU box reports 256 logical CPUs and grants 16)
+int usable_cpus() {
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    double period = 0.0;
+    if (std::fscanf(f, "%31s %lf", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0.0)
+      n = std::min(n, std::max(1, (int)(std::atof(quota) / period)));
+    std::fclose(f);
+  }
+  return n;
+}
+
+// fn(begin, end) over [0, n) in contiguous pieces on the usable CPUs; small ranges, or a box that cannot start threads,
+// run on the caller's.  For the per-triangle / per-leaf-entry loops of the flattening (independent items).
+template <class F> void parallel_for(size_t n, size_t min_per_thread, F fn) {
+  int threads = (int)std::min<size_t>((size_t)std::min(usable_cpus(), 32), n / std::max<size_t>(min_per_thread, 1));
+  if (const char* e = std::getenv("RPTGPU_BUILD_THREADS")) threads = std::min(threads, std::max(1, std::atoi(e)));
+  if (threads <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> pool;
+  const size_t step = (n + (size_t)threads - 1) / (size_t)threads;
+  size_t done = 0;
+  try {
+    for (; done < n; done += step) {
+      const size_t b = done, e = std::min(n, done + step);
+      pool.emplace_back([=] { fn(b, e); });
+    }
+  } catch (const std::system_error&) { // thread limit: the rest here
+    fn(done, n);
+  }
+  for (std::thread& t : pool) t.join();
+}
+
 constexpr double SCORE_THRESHOLD = 0.85; // kdtree.rs:6
 
 // median of the multiset `v` as `median(&sorted)` (kdtree.rs:347-355) would return it, without
@@ -220,23 +257,6 @@ void build_subtree(const std::vector<Box>& boxes, std::vector<uint32_t>& idx, ui
 
 } // namespace
 
-// CPUs this process may actually run on: the affinity mask and the cgroup v2 quota, not the machine's core count
-// (a GPU box reports 256 logical CPUs and grants 16)
-static int usable_cpus() {
-  int n = (int)std::max(1u, std::thread::hardware_concurrency());
-  cpu_set_t set;
-  CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
-  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    char quota[32] = {0};
-    double period = 0.0;
-    if (std::fscanf(f, "%31s %lf", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0.0)
-      n = std::min(n, std::max(1, (int)(std::atof(quota) / period)));
-    std::fclose(f);
-  }
-  return n;
-}
-
 void kd_build(const std::vector<Box>& boxes, KdBuild& out, int threads) {
   std::vector<uint32_t> idx(boxes.size());
   Box root;
@@ -331,7 +351,8 @@ void fill_leaf_boxes(FlatScene& fs, int tree, int64_t tri_base /* < 0: a GROUP t
   }
   size_t nrefs = fs.refs.size() - t.ref_base;
   fs.lbox.resize(fs.refs.size());
-  for (size_t j = 0; j < nrefs; j++) {
+  parallel_for(nrefs, 16384, [&](size_t j0, size_t j1) {
+  for (size_t j = j0; j < j1; j++) {
     uint32_t tri = fs.refs[t.ref_base + j];
     const Box& b = boxes[tri];
     uint32_t q[6];
@@ -352,6 +373,7 @@ void fill_leaf_boxes(FlatScene& fs, int tree, int64_t tri_base /* < 0: a GROUP t
     lb.w[0] = q[0] | (q[1] << 16); lb.w[1] = q[2] | (q[3] << 16); lb.w[2] = q[4] | (q[5] << 16); lb.w[3] = full ? 1u : 0u;
     fs.lbox[t.ref_base + j] = lb;
   }
+  });
 }
 
 struct Flattener {
@@ -459,15 +481,17 @@ struct Flattener {
           std::vector<Box> boxes(s.num_triangles);
           fs.tris.resize(base + s.num_triangles);
           fs.trix.resize(base + s.num_triangles);
-          for (uint64_t i = 0; i < s.num_triangles; i++) {
-            const RptTriangle& t = s.triangles[i];
-            std::memcpy(fs.tris[base + i].v, &t, sizeof(double) * 18);
-            fill_trix(t, fs.trix[base + i]);
-            for (int k = 0; k < 3; k++) { // glm::min3 / max3, mesh.rs:40-45
-              boxes[i].lo[k] = std::fmin(std::fmin(t.v1[k], t.v2[k]), t.v3[k]);
-              boxes[i].hi[k] = std::fmax(std::fmax(t.v1[k], t.v2[k]), t.v3[k]);
+          parallel_for(s.num_triangles, 16384, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+              const RptTriangle& t = s.triangles[i];
+              std::memcpy(fs.tris[base + i].v, &t, sizeof(double) * 18);
+              fill_trix(t, fs.trix[base + i]);
+              for (int k = 0; k < 3; k++) { // glm::min3 / max3, mesh.rs:40-45
+                boxes[i].lo[k] = std::fmin(std::fmin(t.v1[k], t.v2[k]), t.v3[k]);
+                boxes[i].hi[k] = std::fmax(std::fmax(t.v1[k], t.v2[k]), t.v3[k]);
+              }
             }
-          }
+          });
           int tr = add_tree(boxes, base);
           if (tr < 0) return RPTGPU_E_TREE_TOO_DEEP;
           // leaf-ordered copies of the intersection records: entry j of refs[] <-> lrec[j], so a
@@ -477,7 +501,9 @@ struct Flattener {
             const rptdev::Tree& t = fs.trees[tr];
             size_t nrefs = fs.refs.size() - t.ref_base;
             fs.lrec.resize(fs.refs.size());
-            for (size_t j = 0; j < nrefs; j++) fs.lrec[t.ref_base + j] = fs.trix[base + fs.refs[t.ref_base + j]];
+            parallel_for(nrefs, 16384, [&](size_t j0, size_t j1) {
+              for (size_t j = j0; j < j1; j++) fs.lrec[t.ref_base + j] = fs.trix[base + fs.refs[t.ref_base + j]];
+            });
           }
           fill_leaf_boxes(fs, tr, (int64_t)base, boxes);
           mesh_cache[key] = tr;
