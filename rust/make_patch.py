@@ -9,7 +9,7 @@
     for whoever has a Rust toolchain.
 
 Usage (needs the reference checkout; only the PATCH is committed, never reference sources):
-    python rust/make_patch.py /root/reference
+    python rust/make_patch.py /root/reference [output file, default rust/rpt.patch]
 The new files of the patch (src/rng.rs, src/gpu.rs, examples/dump_golden.rs) live next to this script under
 rust/rpt_additions/ and are original code of this repository.
 """
@@ -52,6 +52,7 @@ def rng_type(s, rel):
 
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    dest = sys.argv[2] if len(sys.argv) > 2 else os.path.join(HERE, "rpt.patch")  # (tests regenerate into a temp file)
     tmp = tempfile.mkdtemp(prefix="rpt_patch_")
     a, b = os.path.join(tmp, "a"), os.path.join(tmp, "b")
     for d in (a, b):
@@ -228,8 +229,8 @@ philox = []
 
     out = subprocess.run(["diff", "-ruN", "a", "b"], cwd=tmp, capture_output=True, text=True).stdout
     out = re.sub(r"^(---|\+\+\+) (\S+)\t.*$", r"\1 \2", out, flags=re.M)  # no timestamps
-    open(os.path.join(HERE, "rpt.patch"), "w").write(out)
-    print("wrote rust/rpt.patch: %d lines, %d files" % (out.count("\n"), out.count("\ndiff -ruN") + 1))
+    open(dest, "w").write(out)
+    print("wrote %s: %d lines, %d files" % (dest, out.count("\n"), out.count("\ndiff -ruN") + 1))
     shutil.rmtree(tmp)
 
 

@@ -169,6 +169,20 @@ def test_patch_covers_the_closed_shape_set_and_is_current():
             shutil.rmtree(tmp)
 
 
+def test_committed_patch_is_what_the_generator_makes_today(tmp_path):
+    """rust/rpt.patch regenerated from the reference checkout and rust/rpt_additions/ equals the committed file: an edit
+    of gpu.rs / rng.rs / dump_golden.rs (or of the generator) without re-running make_patch.py is caught here, and so is
+    a reference whose anchors moved.  (No reference checkout — the GPU box — nothing to regenerate from: skipped.)"""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("no reference checkout here")
+    out = str(tmp_path / "rpt.patch")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "rust", "make_patch.py"), ref, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fresh, committed = open(out).read(), open(os.path.join(ROOT, "rust", "rpt.patch")).read()
+    assert fresh == committed, "rust/rpt.patch is stale: run `python rust/make_patch.py /root/reference`"
+
+
 def test_philox_stream_of_the_patch_is_the_oracles(oracle):
     """rust/rpt_additions/rng.rs restated in Python line by line gives the oracle's draws."""
     src = open(os.path.join(ROOT, "rust", "rpt_additions", "rng.rs")).read()
