@@ -148,6 +148,7 @@ struct rptgpu_scene {
   bool ext_shapes = false;       // scene has a shape only the *_ext kernel builds implement
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
+  std::vector<rptdev::Light> host_lights; // (what launch decisions need of the lights)
   std::vector<uint32_t> cnt_host;  // the per-depth counters read back from the device
   bool has_deep = false;
   int rays_in_kernel = 0;          // RPTGPU_RAYS_IN_KERNEL: rptgpu_closest_hit keeps to rpt_extend_rays also when the scene has deep trees
@@ -334,7 +335,10 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
       const uint64_t threads = (uint64_t)std::max(1, h->num_cus * 4) / 4 * RPT_TT_WAVES * 256;
       const uint64_t levels = (uint64_t)(rptdev::KD_MAX_STACK - RPT_TT_LEVELS);
       h->spill_node.alloc(levels * threads); h->spill_ts.alloc(levels * threads); h->spill_bmax.alloc(levels * threads);
-      h->spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads};
+      uint32_t zeros_common = 0; // every shadow ray towards an axis-parallel directional light has a zero component
+      for (const rptdev::Light& l : h->host_lights)
+        if (l.kind == RPT_LIGHT_DIRECTIONAL && (l.vec[0] == 0.0 || l.vec[1] == 0.0 || l.vec[2] == 0.0)) zeros_common = 1;
+      h->spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads, zeros_common};
     }
     if (h->sort_rays) {
       h->sort_kin.alloc(cap); h->sort_kout.alloc(cap); h->sort_vin.alloc(cap);
@@ -817,6 +821,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->ext_shapes = fs.nested_mesh;
     for (const rptdev::Inst& in : fs.insts) h->ext_shapes = h->ext_shapes || in.kind == RPT_SHAPE_MONOMIAL;
     for (const rptdev::Light& l : fs.lights) h->light_casts.push_back(l.kind != RPT_LIGHT_AMBIENT ? 1 : 0);
+    h->host_lights = fs.lights;
     h->insts.upload(fs.insts, h->stream);
     h->trees.upload(fs.trees, h->stream);
     h->nodes.upload(fs.nodes, h->stream);

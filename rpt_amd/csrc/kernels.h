@@ -44,6 +44,7 @@ struct StackSpill {
   double* ts;
   double* bmax;
   uint32_t threads;
+  uint32_t zeros_common; // scene hint for launch_query: rays with a zero direction component are frequent (full grid for their kernel)
 };
 
 // accounting hook of launch_query: called with (ctx, kind, 0) before and (ctx, kind, 1) after the launches of

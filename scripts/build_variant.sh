@@ -12,5 +12,5 @@ COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 if [ -z "$NOEXT" ]; then /opt/rocm/bin/hipcc $COMMON -ffp-contract=off $FLAGS -c kernels_strict_ext.hip -o $B/kernels_strict_ext.o & else cp build/kernels_strict_ext.o $B/; fi
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off $FLAGS -x hip -c api.cpp -o $B/api.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/librptgpu_$NAME.so $B/kernels_strict.o $B/api.o $B/kernels_strict_ext.o build/host_scene.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/librptgpu_$NAME.so $B/kernels_strict.o $B/api.o $B/kernels_strict_ext.o build/host_scene.o build/kdbuild.o
 echo built ../lib/librptgpu_$NAME.so
