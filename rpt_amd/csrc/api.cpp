@@ -86,8 +86,17 @@ Rccl load_rccl() {
     return r;
   }
   std::string err;
+  // A copy the process already has (PyTorch-ROCm brings its own librccl.so) is used as it is; otherwise ours is opened
+  // RTLD_LOCAL: a second librccl.so loaded later by someone else must not bind its symbols to this one — two copies
+  // with RTLD_GLOBAL ended in "double free or corruption" at process exit (pytest importing torch after the first
+  // rptgpu_comm_* call)
+  for (const char* name : {"librccl.so", "librccl.so.1"}) {
+    r.so = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (r.so) break;
+  }
   for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-    r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.so) break;
+    r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (r.so) break;
     const char* e = dlerror(); // ONE call: dlerror() clears the message it returns
     if (e && err.empty()) err = e;
@@ -122,6 +131,8 @@ struct rptgpu_scene {
   DevBuf<rptdev::Tri> tris;
   DevBuf<rptdev::TriX> trix;
   DevBuf<rptdev::LeafBox> lbox;
+  DevBuf<rptdev::LeafBox> obj_box; // flat scenes' object filter (FlatLayout::obj_box / obj_grid)
+  DevBuf<double> obj_grid;
   DevBuf<rptdev::Material> materials;
   DevBuf<rptdev::Light> lights;
   DevBuf<double> env_texels;
@@ -476,7 +487,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       if (std::getenv("RPTGPU_PRINT_LAUNCH"))
         std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp, "
                      "LDS %u B per wave (%u clamp-record levels)\n",
-                     flat ? "KdFlat" : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds, flat ? lay.rec_levels : 0u);
+                     flat ? (lay.obj_filter ? "KdFlat, object filter" : "KdFlat") : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds, flat ? lay.rec_levels : 0u);
       h->counters.alloc(4);
       h->pcounters.alloc(16);
       HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
@@ -808,6 +819,26 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         h->plane_vals.upload(planes, h->stream);
         HIP_TRY(hipStreamSynchronize(h->stream)); // `planes` dies with this block
         lay.plane_vals = h->plane_vals.p;
+      }
+      // many small objects and no plane table (a room of polygons rather than C2's five walls): the object filter
+      // (host_scene.cpp fill_object_boxes).  RPTGPU_OBJECT_FILTER_MIN: from how many objects (default 8; 0 = never)
+      {
+        int min_objects = 8;
+        if (const char* e = std::getenv("RPTGPU_OBJECT_FILTER_MIN")) min_objects = std::atoi(e);
+        const uint64_t every = fs.num_objects >= 64 ? ~0ull : (1ull << fs.num_objects) - 1ull;
+        if (!lay.plane_cnt && min_objects > 0 && fs.num_objects >= min_objects && fs.obj_filter_ok &&
+            (fs.obj_always & every) != every &&
+            up16(off + (uint64_t)fs.num_objects * 6 * sizeof(double)) + REC_LEVEL <= WAVE_LDS) {
+          lay.obj_filter = 1;
+          lay.obj_always = fs.obj_always & every;
+          lay.off_obox = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 6 * sizeof(double));
+          h->obj_box.upload(fs.obj_lbox, h->stream);
+          std::vector<double> grid(fs.obj_grid, fs.obj_grid + 12);
+          h->obj_grid.upload(grid, h->stream);
+          HIP_TRY(hipStreamSynchronize(h->stream)); // `grid` dies with this block
+          lay.obj_box = h->obj_box.p;
+          lay.obj_grid = h->obj_grid.p;
+        }
       }
       lay.off_rec = (uint32_t)off;
       if (off > WAVE_LDS) {

@@ -338,42 +338,119 @@ void fill_trix(const RptTriangle& t, rptdev::TriX& x) {
 // whose barycentric system is ill-conditioned (sliver: rounding in mesh.rs:64-73 could accept a point that is not
 // near the triangle) or that has a non-finite vertex gets the whole grid, i.e. it is never filtered.  GROUP trees get
 // the boxes of their children the same way (a child's hit point lies on the child, hence in its bounding box).
+rptdev::LeafBox quantise_box(const Box& b, const double* qlo, const double* qscale, bool full) {
+  uint32_t q[6];
+  for (int k = 0; k < 3 && !full; k++) {
+    double a = std::floor((b.lo[k] - qlo[k]) / qscale[k]) - 1.0;
+    double c = std::ceil((b.hi[k] - qlo[k]) / qscale[k]) + 1.0;
+    if (!(a == a) || !(c == c)) { full = true; break; }
+    q[k] = (uint32_t)std::fmin(std::fmax(a, 0.0), 65535.0);
+    q[3 + k] = (uint32_t)std::fmin(std::fmax(c, 0.0), 65535.0);
+  }
+  if (full) { q[0] = q[1] = q[2] = 0; q[3] = q[4] = q[5] = 65535; }
+  rptdev::LeafBox lb;
+  lb.w[0] = q[0] | (q[1] << 16); lb.w[1] = q[2] | (q[3] << 16); lb.w[2] = q[4] | (q[5] << 16); lb.w[3] = full ? 1u : 0u;
+  return lb;
+}
+void grid_over(const double* bounds, double* qlo, double* qscale) {
+  for (int k = 0; k < 3; k++) {
+    double ext = bounds[3 + k] - bounds[k];
+    qscale[k] = (ext > 0.0 && std::isfinite(ext)) ? ext / 65529.0 : 1.0;
+    qlo[k] = bounds[k] - 2.0 * qscale[k];
+  }
+}
+bool sliver(const rptdev::TriX& x) { // ill-conditioned barycentric system, degenerate or NaN: never filtered
+  return !(x.denom > 1e-10 * (x.d00 * x.d11)) || !std::isfinite(x.denom);
+}
+
+// Spheres (and monomial surfaces) are tested by solving a polynomial whose coefficients grow with the square of the
+// origin's distance in OBJECT units: from far away Sphere::intersect accepts lines that miss the sphere (kernels/
+// shapes.inc boxray_make).  The device bounds the origin's distance to 1e7 grid steps when quadrics are filtered; a
+// sphere whose smallest semi-axis is below 64 steps (1e-3 of the grid) is not filtered at all, nor is a monomial surface.
+bool quadric_too_small(const rptdev::Inst& in, const double* qscale) {
+  if (in.kind == RPT_SHAPE_MONOMIAL) return true;
+  if (in.kind != RPT_SHAPE_SPHERE) return false;
+  double r_min = 1.0; // smallest singular value of the placement >= 1 / ||M^-1||_F
+  if (in.has_xf) {
+    double b = 0.0;
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) b += in.inv[4 * c + r] * in.inv[4 * c + r];
+    r_min = 1.0 / std::sqrt(b);
+  }
+  const double step = std::fmax(std::fmax(qscale[0], qscale[1]), qscale[2]);
+  return !(r_min >= 64.0 * step);
+}
+
 void fill_leaf_boxes(FlatScene& fs, int tree, int64_t tri_base /* < 0: a GROUP tree, entries are placed shapes */,
-                     const std::vector<Box>& boxes) {
+                     const std::vector<Box>& boxes, const std::vector<rptdev::Inst>* kids = nullptr) {
   rptdev::Tree& t = fs.trees[tree];
   // the grid is two steps larger than the bounds on every side: a coordinate of a primitive maps to [2, 65531], so the
   // outward rounding below (floor - 1, ceil + 1) never reaches the clamp, i.e. a box on a face of the tree's bounds
   // keeps its margin too (tests/test_leaf_boxes.py found the case: a vertex on the bounds, a hit exactly there)
-  for (int k = 0; k < 3; k++) {
-    double ext = t.bounds[3 + k] - t.bounds[k];
-    t.qscale[k] = (ext > 0.0 && std::isfinite(ext)) ? ext / 65529.0 : 1.0;
-    t.qlo[k] = t.bounds[k] - 2.0 * t.qscale[k];
-  }
+  grid_over(t.bounds, t.qlo, t.qscale);
   size_t nrefs = fs.refs.size() - t.ref_base;
   fs.lbox.resize(fs.refs.size());
   parallel_for(nrefs, 16384, [&](size_t j0, size_t j1) {
   for (size_t j = j0; j < j1; j++) {
     uint32_t tri = fs.refs[t.ref_base + j];
     const Box& b = boxes[tri];
-    uint32_t q[6];
-    bool full = false;
-    if (tri_base >= 0) {
-      const rptdev::TriX& x = fs.trix[tri_base + tri];
-      full = !(x.denom > 1e-10 * (x.d00 * x.d11)) || !std::isfinite(x.denom); // sliver / degenerate / NaN
-    }
-    for (int k = 0; k < 3 && !full; k++) {
-      double a = std::floor((b.lo[k] - t.qlo[k]) / t.qscale[k]) - 1.0;
-      double c = std::ceil((b.hi[k] - t.qlo[k]) / t.qscale[k]) + 1.0;
-      if (!(a == a) || !(c == c)) { full = true; break; }
-      q[k] = (uint32_t)std::fmin(std::fmax(a, 0.0), 65535.0);
-      q[3 + k] = (uint32_t)std::fmin(std::fmax(c, 0.0), 65535.0);
-    }
-    if (full) { q[0] = q[1] = q[2] = 0; q[3] = q[4] = q[5] = 65535; }
-    rptdev::LeafBox lb;
-    lb.w[0] = q[0] | (q[1] << 16); lb.w[1] = q[2] | (q[3] << 16); lb.w[2] = q[4] | (q[5] << 16); lb.w[3] = full ? 1u : 0u;
+    const bool full = tri_base >= 0 ? sliver(fs.trix[tri_base + tri]) : (kids && quadric_too_small((*kids)[tri], t.qscale));
+    rptdev::LeafBox lb = quantise_box(b, t.qlo, t.qscale, full);
     fs.lbox[t.ref_base + j] = lb;
   }
   });
+}
+
+// The same filter one level up, for scenes that are a list of many small objects (every tree a single leaf: the flat
+// path kernel, kernels/paths.inc flat_query_filtered).  The reference tests every object of scene.objects against every
+// ray (renderer.rs:211-220); an object's intersect can only accept a hit point that lies on the object, hence inside its
+// bounding_box (the triangles' boxes for a mesh, Transformed::bounding_box shape.rs:153-176 for a placed sphere / cube /
+// mesh), so a ray that does not cross that box — enlarged by a grid step, tested in f32 — inside [t_min, record.time]
+// skips the object's test with nothing changed.  Never filtered: unbounded objects (Plane), boxes that are not finite,
+// meshes with a sliver triangle (see above), placements whose matrices are so ill-conditioned that the world-space
+// point o + t d and the object-space point the test accepted could be a noticeable fraction of a grid step apart.
+void fill_object_boxes(FlatScene& fs, const std::vector<Box>& world, const std::vector<char>& bounded) {
+  const size_t n = world.size();
+  fs.obj_filter_ok = n >= 1 && n <= 64;
+  fs.obj_always = ~0ull;
+  fs.obj_lbox.assign(n, quantise_box(empty_box(), fs.obj_grid, fs.obj_grid + 3, true));
+  if (!fs.obj_filter_ok) return;
+  std::vector<char> ok(n, 0);
+  Box all = empty_box();
+  for (size_t i = 0; i < n; i++) {
+    const rptdev::Inst& in = fs.insts[i];
+    if (in.kind != RPT_SHAPE_SPHERE && in.kind != RPT_SHAPE_CUBE && in.kind != RPT_SHAPE_PLANE && in.kind != RPT_SHAPE_MESH) {
+      fs.obj_filter_ok = false; // a kind the filtered walk does not dispatch per lane (group, monomial surface)
+      return;
+    }
+    bool good = bounded[i] != 0;
+    for (int k = 0; k < 3 && good; k++) good = std::isfinite(world[i].lo[k]) && std::isfinite(world[i].hi[k]) && world[i].lo[k] <= world[i].hi[k];
+    if (good && in.kind == RPT_SHAPE_MESH) {
+      const rptdev::Tree& t = fs.trees[in.tree];
+      for (uint32_t j = 0; j < t.num_prims && good; j++) good = !sliver(fs.trix[t.prim_base + j]);
+    }
+    if (good && in.has_xf) { // condition number (Frobenius) of the placement
+      double a = 0.0, b = 0.0;
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) { a += in.fwd[4 * c + r] * in.fwd[4 * c + r]; b += in.inv[4 * c + r] * in.inv[4 * c + r]; }
+      good = std::isfinite(a) && std::isfinite(b) && a * b < 1e8; // cond < 1e4
+    }
+    ok[i] = good ? 1 : 0;
+    if (good) all = merge(all, world[i]);
+  }
+  double bounds[6];
+  for (int k = 0; k < 3; k++) { bounds[k] = all.lo[k]; bounds[3 + k] = all.hi[k]; }
+  for (int k = 0; k < 6; k++)
+    if (!std::isfinite(bounds[k])) return; // nothing to filter: obj_always stays all ones
+  grid_over(bounds, fs.obj_grid, fs.obj_grid + 3);
+  std::memcpy(fs.obj_grid + 6, bounds, sizeof(bounds));
+  fs.obj_always = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (ok[i] && quadric_too_small(fs.insts[i], fs.obj_grid + 3)) ok[i] = 0;
+    if (ok[i]) fs.obj_lbox[i] = quantise_box(world[i], fs.obj_grid, fs.obj_grid + 3, false);
+    if (!ok[i] || fs.obj_lbox[i].w[3]) fs.obj_always |= 1ull << i;
+  }
+  if (n < 64) fs.obj_always &= (1ull << n) - 1ull;
 }
 
 struct Flattener {
@@ -539,7 +616,7 @@ struct Flattener {
         if (tr < 0) return RPTGPU_E_TREE_TOO_DEEP;
         // the children's boxes (Sphere / Cube / Mesh bounds through Transformed::bounding_box, shape.rs:153-176) contain
         // every point their intersect can return; the same filter as for triangles applies
-        fill_leaf_boxes(fs, tr, -1, boxes);
+        fill_leaf_boxes(fs, tr, -1, boxes, &kids);
         group_children.push_back({tr, std::move(kids)});
         in.tree = tr;
         const rptdev::Tree& t = fs.trees[tr];
@@ -571,10 +648,14 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const Bui
   Flattener fl{fs, err, {}, build, {}};
   fs.num_objects = (int32_t)sc.num_objects;
   fs.insts.resize(sc.num_objects);
+  std::vector<Box> world(sc.num_objects, empty_box()); // Bounded objects: their bounding_box (the object filter's)
+  std::vector<char> world_ok(sc.num_objects, 0);
   for (uint64_t i = 0; i < sc.num_objects; i++) {
     rptdev::Inst in;
-    int rc = fl.fill_inst(sc.objects[i].shape, in, nullptr, nullptr, 0);
+    bool bounded = false;
+    int rc = fl.fill_inst(sc.objects[i].shape, in, &world[i], &bounded, 0);
     if (rc != RPTGPU_OK) return rc;
+    world_ok[i] = bounded ? 1 : 0;
     in.material = (int32_t)fs.materials.size();
     fs.insts[i] = in;
     rptdev::Material m;
@@ -628,6 +709,7 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const Bui
     }
     fs.lights.push_back(dl);
   }
+  fill_object_boxes(fs, world, world_ok);
   for (auto& g : fl.group_children) { // now place GROUP children and patch prim_base
     fs.trees[g.first].prim_base = (uint32_t)fs.insts.size();
     fs.insts.insert(fs.insts.end(), g.second.begin(), g.second.end());

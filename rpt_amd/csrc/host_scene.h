@@ -55,6 +55,13 @@ struct FlatScene {
   int32_t num_objects = 0;
   int32_t num_shadow_lights = 0;
   uint32_t max_tree_depth = 0;
+  // flat scenes' object filter (kernels/paths.inc flat_query_filtered): one conservative box per TOP-LEVEL object on a
+  // grid over all bounded ones; bit k of obj_always: object k is never filtered.  obj_filter_ok: every object is of a
+  // kind the filtered walk handles (sphere, cube, plane, mesh) and there are at most 64 of them
+  std::vector<rptdev::LeafBox> obj_lbox;
+  double obj_grid[12] = {0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0}; // qlo[3], qscale[3], bounds[6]
+  uint64_t obj_always = ~0ull;
+  bool obj_filter_ok = false;
   uint32_t trees_built_on_device = 0; // how many of the trees kd_build_device made (diagnostics)
   bool nested_mesh = false; // some KdTree<Box<dyn Bounded>> child is a Mesh, a MonomialSurface or another group:
                             // the scene needs the extended kernel builds

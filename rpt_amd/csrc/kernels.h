@@ -20,6 +20,14 @@ struct FlatLayout {
   // by every mesh whose box uses that plane (the walls of C2 have 30 faces on 6 distinct planes)
   uint32_t off_qtab, plane_cnt;  // plane_cnt: 4 bits per axis; 0 = feature off
   const double* plane_vals;      // [3][4] in device memory
+  // the object filter of flat scenes with many objects and no plane table (kernels/paths.inc flat_query_filtered): a
+  // conservative 16-bit box per top-level object on a grid over all of them, tested in f32 before the object's own
+  // (exact) test; bit k of obj_always = object k is never filtered (a Plane, a mesh with a sliver, ...)
+  uint32_t obj_filter;           // 0 = off
+  uint32_t off_obox;             // [objects][6] doubles in LDS: the bounds of MESH objects (their exact slab test)
+  const rptdev::LeafBox* obj_box; // [objects] in device memory
+  const double* obj_grid;        // qlo[3], qscale[3], bounds[6] of the grid, device memory
+  uint64_t obj_always;
 };
 
 // buffers of the optional ray sort in front of a per-tree traversal (all sized for the query's n)

@@ -47,3 +47,27 @@ print("RC", lib.rptgpu_comm_unique_id(None), _abi.RPTGPU_E_INVALID_ARGUMENT)
     assert r.returncode == 0, r.stderr[-2000:]
     rcs = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("RC")]
     assert len(rcs) == 2 and all(a[1] == a[2] for a in rcs), r.stdout
+
+
+def test_the_library_rccl_and_pytorch_rccl_coexist_until_process_exit():
+    # PyTorch-ROCm ships its own librccl.so.  The library used to dlopen /opt/rocm's RTLD_GLOBAL; a torch imported
+    # AFTER the first rptgpu_comm_* call then bound part of its copy to ours and the process died at exit with
+    # "double free or corruption" (rc 134 with every test passed).  Now: a copy that is already loaded is reused,
+    # otherwise ours is opened RTLD_LOCAL.  Both orders must leave with rc 0 (no GPU needed: unique_id may fail).
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r)
+from rpt_amd import _abi
+order = sys.argv[1]
+if order == "torch_first":
+    import torch
+lib = _abi.load_library()
+buf = (C.c_uint8 * _abi.RPTGPU_UNIQUE_ID_BYTES)()
+print("RC", lib.rptgpu_comm_unique_id(buf))
+if order == "torch_last":
+    import torch
+print("END")
+""" % ROOT
+    for order in ("torch_last", "torch_first"):
+        r = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "END" in r.stdout, (order, r.returncode, r.stdout[-300:], r.stderr[-300:])

@@ -537,6 +537,17 @@ def test_flat_scenes_batched_leaf_tests_match_the_oracle(oracle, n_walls, transf
         pp = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=flags)
         img = g.render_batch(cam, pp)
         assert (img == ref).all(), (n_walls, flags, np.abs(img - ref).max())
+    # scenes of 8..64 objects run the flat kernel behind the object filter (paths.inc flat_query_filtered); the same
+    # scene without it (the batched runs alone), and with it from the first object on
+    for min_objects in ("0", "1"):
+        os.environ["RPTGPU_OBJECT_FILTER_MIN"] = min_objects
+        try:
+            g2 = GpuScene(scene, 0)
+        finally:
+            del os.environ["RPTGPU_OBJECT_FILTER_MIN"]
+        img = g2.render_batch(cam, p)
+        g2.close()
+        assert (img == ref).all(), (n_walls, "RPTGPU_OBJECT_FILTER_MIN=" + min_objects, np.abs(img - ref).max())
     # closest hits and random secondary rays through rptgpu_closest_hit as well
     rs = np.random.RandomState(n_walls)
     o = rs.uniform(-2.5, 2.5, (4000, 3))
@@ -545,6 +556,53 @@ def test_flat_scenes_batched_leaf_tests_match_the_oracle(oracle, n_walls, transf
     t0, n0, ob0 = oracle.OracleScene(scene).closest_hit(o, d)
     t1, n1, ob1 = g.closest_hit(o, d)
     assert (t0 == t1).all() and (ob0 == ob1).all() and (n0.view(np.int64) == n1.view(np.int64)).all()
+    g.close()
+
+
+def test_object_filter_far_cameras_axis_parallel_rays_and_unfilterable_objects(oracle):
+    # the object filter (host_scene.cpp fill_object_boxes, paths.inc flat_query_filtered) where its f32 arithmetic and
+    # its exemptions are stressed: an unbounded Plane among the objects, a sphere a thousand times smaller than the
+    # scene, a placement with condition number 1e5 (exempt), a mesh with a sliver (exempt), objects in the corners of
+    # the grid, a directional light along an axis (shadow rays with two zero components), cameras inside an object's
+    # box, far outside the grid (1e3 and 1e7 scene sizes away: the latter switches the filter off per ray) and looking
+    # exactly along an axis
+    rs = np.random.RandomState(11)
+    S = rpt_amd.Scene()
+    S.add(rpt_amd.Object(rpt_amd.plane((0.0, 1.0, 0.0), -1.0)).material(rpt_amd.Material.diffuse((0.6, 0.6, 0.6))))
+    for i in range(10):
+        c = rs.uniform(-2.0, 2.0, 3)
+        a = rs.randn(3); a /= np.linalg.norm(a)
+        b = np.cross(a, rs.randn(3)); b /= np.linalg.norm(b)
+        k = (3, 4, 5, 7)[i % 4]
+        verts = [tuple(c + 0.8 * (math.cos(t) * a + math.sin(t) * b)) for t in np.linspace(0, 2 * math.pi, k, endpoint=False)]
+        shape = rpt_amd.polygon(verts)
+        if i % 3 == 2:
+            shape = shape.rotate_y(0.4 * i).translate((0.1, 0.0, -0.1))
+        S.add(rpt_amd.Object(shape).material(rpt_amd.Material.diffuse(tuple(rs.uniform(0.3, 0.9, 3)))))
+    S.add(rpt_amd.Object(rpt_amd.sphere().scale((2e-3, 2e-3, 2e-3)).translate((0.2, 0.3, 1.0))).material(rpt_amd.Material.specular((0.9, 0.2, 0.2), 0.3)))
+    S.add(rpt_amd.Object(rpt_amd.sphere().scale((1.0, 1e-5, 1.0)).translate((-1.0, 0.5, 0.0))).material(rpt_amd.Material.diffuse((0.2, 0.9, 0.2))))
+    S.add(rpt_amd.Object(rpt_amd.cube().rotate_y(0.7).scale((0.5, 1.5, 0.5)).translate((2.5, 0.0, -2.5))).material(rpt_amd.Material.clear(1.5, 0.05)))
+    S.add(rpt_amd.Object(rpt_amd.cube().translate((-3.0, -0.5, 3.0))))                      # a corner of the grid, axis-aligned
+    S.add(rpt_amd.Object(rpt_amd.sphere().translate((3.0, 2.0, 3.0))).material(rpt_amd.Material.metallic_((0.9, 0.9, 0.9), 0.1)))
+    S.add(rpt_amd.Object(rpt_amd.polygon([(0.0, 1.5, 0.0), (0.0, 1.5, 0.0), (1.0, 1.5, 0.0), (1.0, 1.5000000001, 1e-9)])))  # sliver
+    S.add(rpt_amd.Light.Directional((0.4, 0.4, 0.4), (0.0, -1.0, 0.0)))
+    S.add(rpt_amd.Light.Point((30.0, 30.0, 30.0), (0.5, 3.0, 0.5)))
+    S.add(rpt_amd.Light.Object(rpt_amd.Object(rpt_amd.sphere().scale((0.2, 0.2, 0.2)).translate((0.0, 2.5, 0.0)))
+                               .material(rpt_amd.Material.light((1.0, 1.0, 1.0), 40.0))))
+    cams = [rpt_amd.Camera.look_at((0.0, 0.8, 6.0), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 0.9),
+            rpt_amd.Camera.look_at((-3.0, -0.4, 3.0), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 1.2),           # inside the corner cube
+            rpt_amd.Camera.look_at((0.0, 2.0e3, 6.0e3), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 0.0012),
+            rpt_amd.Camera.look_at((0.0, 0.0, 6.0e7), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 1.2e-7),
+            rpt_amd.Camera(eye=(0.2, 0.3, 5.0), direction=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), fov=0.5)]
+    g = GpuScene(S, 0)
+    osc = oracle.OracleScene(S)
+    for ci, cam in enumerate(cams):
+        p = make_params(48, 32, 4, 3, seed=500 + ci)
+        ref = osc.render(cam, p, threads=0)
+        img = g.render_batch(cam, p)
+        same = (img == ref) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), (ci, np.abs(img - ref).max())
+        assert (ref != 0).any()
     g.close()
 
 
