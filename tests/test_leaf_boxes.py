@@ -39,7 +39,7 @@ def outward(x, sign):
         return (x + np.float32(sign) * (np.abs(x) * np.float32(1.2e-7) + np.float32(1e-30))).astype(np.float32)
 
 
-def box_pass(q, scale, lo, o, d, t_lo, t_hi):
+def box_pass(q, scale, lo, o, d, t_lo, t_hi, far=1e12):
     """boxray_make + box_window + leaf_box_pass for pairs (q[i], ray i); returns (pass, filter_on).  The device evaluates
     the slabs in f32 with fmaf, counted from t0 = max(root slab entry, 0); numpy has no fmaf: q * a is exact in f64
     (16 x 24 bits), so f64 add + one rounding to f32 differs from it only in rare double-rounding ties."""
@@ -55,7 +55,7 @@ def box_pass(q, scale, lo, o, d, t_lo, t_hi):
         u = (lo - o) * r
         b = np.where(z, -g * BOX_PAR, u - t0[:, None])
         ok = np.where(z, np.abs(g) < 1e6, (np.abs(a) > 1e-30) & (np.abs(a) < 1e30) & (np.abs(b) < 1e6 * np.abs(a))
-                      & (np.abs(u) < 1e12 * np.abs(a)))
+                      & (np.abs(u) < far * np.abs(a)))
         on = ~z.all(axis=1) & ok.all(axis=1) & (np.abs(t0) < 1e300)
         a32, b32 = a.astype(np.float32), b.astype(np.float32)
         t0_ = (q[:, 0:3] * a32.astype(np.float64) + b32.astype(np.float64)).astype(np.float32)
@@ -183,3 +183,115 @@ def test_slivers_are_never_filtered():
     degenerate = np.concatenate([a, a, a + e], axis=1)     # zero area: denom == 0
     _, _, _, full = quantise(degenerate, lo, hi)
     assert full.all()
+
+
+# ---- the same filter in front of whole objects: placed spheres and cubes -------------------------------------------
+# (group-tree children since round 2, top-level objects of flat scenes since round 3: host_scene.cpp fill_object_boxes)
+def random_placements(rs, n, smin, smax):
+    """M = T R S (rotation by a random orthogonal matrix, scales in [smin, smax]): (M 3x3, translation, inverse 3x3)"""
+    qm, _ = np.linalg.qr(rs.randn(n, 3, 3))
+    sc = np.exp(rs.uniform(np.log(smin), np.log(smax), (n, 3)))
+    lin = qm * sc[:, None, :]
+    tr = rs.uniform(-3.0, 3.0, (n, 3))
+    return lin, tr, np.linalg.inv(lin)
+
+
+def world_boxes(lin, tr, half):
+    """Transformed::bounding_box (shape.rs:153-176): the box of the eight transformed corners of [-half, half]^3"""
+    corners = np.array([[sx, sy, sz] for sx in (-half, half) for sy in (-half, half) for sz in (-half, half)])
+    w = np.einsum("nij,cj->nci", lin, corners) + tr[:, None, :]
+    return w.min(axis=1), w.max(axis=1)
+
+
+def to_object_space(inv, tr, o, d):
+    lo = np.einsum("nij,nj->ni", inv, o - tr)
+    ld = np.einsum("nij,nj->ni", inv, d)
+    return lo, ld
+
+
+def sphere_hit(lo, ld):
+    """Sphere::intersect (sphere.rs:13-45) with t_min = 1e-12 and record.time = +inf: (accepted, time)"""
+    with np.errstate(all="ignore"):
+        a = (ld * ld).sum(1)
+        b = 2.0 * (lo * ld).sum(1)
+        c = (lo * lo).sum(1) - 1.0
+        disc = b * b - 4.0 * a * c
+        sq = np.sqrt(disc)
+        t1, t2 = (-b - sq) / (2.0 * a), (-b + sq) / (2.0 * a)
+        t = np.where(t1 >= 1e-12, t1, t2)
+        acc = (disc >= 0) & (t >= 1e-12)
+    return acc, t
+
+
+def cube_hit(lo, ld):
+    """Cube::intersect (cube.rs:20-72): slabs of [-0.5, 0.5]^3, entry time if it is >= t_min, else the exit time"""
+    with np.errstate(all="ignore"):
+        t0, t1 = (-0.5 - lo) / ld, (0.5 - lo) / ld
+        near, far = np.fmin(t0, t1), np.fmax(t0, t1)
+        tn, tf = near.max(axis=1), far.min(axis=1)
+        t = np.where(tn >= 1e-12, tn, tf)
+        acc = (tn <= tf) & (t >= 1e-12)
+    return acc, t
+
+
+def quantise_boxes(bmin, bmax, lo, hi):
+    ext = hi - lo
+    scale = np.where((ext > 0) & np.isfinite(ext), ext / GRID, 1.0)
+    lo = lo - 2.0 * scale
+    a = np.clip(np.floor((bmin - lo) / scale) - 1.0, 0.0, 65535.0)
+    c = np.clip(np.ceil((bmax - lo) / scale) + 1.0, 0.0, 65535.0)
+    return np.concatenate([a, c], axis=1), scale, lo
+
+
+def test_object_filter_never_rejects_a_hit_on_a_placed_sphere_or_cube():
+    rs = np.random.RandomState(5)
+    n = 400000
+    for what, half, hit in (("sphere", 1.0, sphere_hit), ("cube", 0.5, cube_hit)):
+        lin, tr, inv = random_placements(rs, n, 0.05, 2.0)          # condition numbers up to 40, semi-axes >= 0.05
+        bmin, bmax = world_boxes(lin, tr, half)
+        lo, hi = bmin.min(0), bmax.max(0)                           # the grid spans all of them (about 10 units)
+        q, scale, glo = quantise_boxes(bmin, bmax, lo, hi)
+        assert (0.05 >= 64.0 * scale).all()                         # no sphere is "too small" (quadric_too_small)
+        # rays aimed at points of the object's surface neighbourhood (so that about half of them graze or miss), from
+        # 0.1 to 3000 units away (1e7 steps are 1500 units: beyond that the filter must be off, see below)
+        p_obj = rs.randn(n, 3)
+        p_obj /= np.linalg.norm(p_obj, axis=1, keepdims=True)
+        p_obj *= half * rs.uniform(0.9, 1.15, (n, 1))
+        if what == "cube":
+            p_obj = rs.uniform(-0.9, 0.9, (n, 3))
+        p = np.einsum("nij,nj->ni", lin, p_obj) + tr
+        dist = 10.0 ** rs.uniform(-1, 3.5, (n, 1))
+        d = rs.randn(n, 3)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o = p - d * dist
+        lo_, ld_ = to_object_space(inv, tr, o, d)
+        acc, t = hit(lo_, ld_)
+        assert 0.2 < acc.mean() < 0.95, (what, acc.mean())
+        for t_lo, t_hi in ((1e-12, np.inf), (t, t), (np.nextafter(t, -np.inf), np.nextafter(t, np.inf))):
+            ok, on = box_pass(q, scale, glo, o, d, t_lo, t_hi, far=1e7)
+            bad = acc & ~ok
+            assert not bad.any(), (what, int(bad.sum()), np.flatnonzero(bad)[:5])
+        assert 0.5 < on.mean() < 0.999, on.mean()                   # on nearby, off from far away
+        # and it filters: against the box of ANOTHER object almost every ray is rejected
+        ok, _ = box_pass(np.roll(q, n // 2, axis=0), scale, glo, o, d, 1e-12, np.inf, far=1e7)
+        assert ok[on].mean() < 0.25, ok[on].mean()
+
+
+def test_why_far_origins_switch_the_filter_off_for_spheres():
+    # from 10^9 radii away Sphere::intersect accepts lines that miss the sphere by many radii (b^2 - 4ac cancels):
+    # the reference's answer is the contract, the box cannot contain such "hits", hence the 1e7-step limit
+    rs = np.random.RandomState(6)
+    n = 200000
+    r = 2e-3
+    o = np.array([0.0, 0.0, 6.0e7]) + rs.randn(n, 3)
+    tgt = rs.randn(n, 3) * 0.5                                       # aimed up to hundreds of radii off the centre
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    acc, t = sphere_hit(o / r, d / r)
+    with np.errstate(all="ignore"):
+        miss = np.linalg.norm(np.cross(-o, d), axis=1)               # distance of the line from the centre
+    wrong = acc & (miss > 10 * r)
+    assert wrong.sum() > 100, int(wrong.sum())
+    q, scale, glo = quantise_boxes(np.full((n, 3), -r), np.full((n, 3), r), np.array([-3.0] * 3), np.array([3.0] * 3))
+    ok, on = box_pass(q, scale, glo, o, d, 1e-12, np.inf, far=1e7)
+    assert not on.any() and ok.all()
