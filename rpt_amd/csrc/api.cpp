@@ -821,9 +821,10 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         lay.plane_vals = h->plane_vals.p;
       }
       // many small objects and no plane table (a room of polygons rather than C2's five walls): the object filter
-      // (host_scene.cpp fill_object_boxes).  RPTGPU_OBJECT_FILTER_MIN: from how many objects (default 8; 0 = never)
+      // (host_scene.cpp fill_object_boxes).  RPTGPU_OBJECT_FILTER_MIN: from how many objects (0 = never).  Measured:
+      // 2 objects -5..-11 % (C1, glass spheres), 5 objects +8 % (basic.rs), 6 objects +4 % (spheres.rs), 29 objects +40 %
       {
-        int min_objects = 8;
+        int min_objects = 5;
         if (const char* e = std::getenv("RPTGPU_OBJECT_FILTER_MIN")) min_objects = std::atoi(e);
         const uint64_t every = fs.num_objects >= 64 ? ~0ull : (1ull << fs.num_objects) - 1ull;
         if (!lay.plane_cnt && min_objects > 0 && fs.num_objects >= min_objects && fs.obj_filter_ok &&
