@@ -80,13 +80,13 @@ enum {
                            fractal_teapots.rs:69).  Children: anything Bounded — SPHERE, CUBE, MESH,
                            MONOMIAL, or another GROUP — each optionally Transformed (a PLANE is not
                            Bounded, kdtree.rs:9-12, and is refused).  MESH children that share one
-                           triangle array (Arc<Mesh>) share one tree on the device.  NESTING: a GROUP may
-                           contain GROUPs whose own children are not GROUPs (scene -> group -> group ->
-                           mesh / primitive); a third group level returns RPTGPU_E_UNSUPPORTED_SHAPE.
-                           The reference nests without bound (kdtree.rs:14-24 forwards Bounded through
-                           Box); on the device every level is one more copy of the traversal inlined into
-                           every kernel that walks a group (registers, code size, minutes of compile
-                           time), so the depth is fixed at what the reference's examples use plus one */
+                           triangle array (Arc<Mesh>) share one tree on the device.  NESTING: GROUPs may
+                           contain GROUPs down to four group levels (scene -> group -> group -> group ->
+                           group -> mesh / primitive); a fifth returns RPTGPU_E_UNSUPPORTED_SHAPE.  The
+                           reference nests without bound (kdtree.rs:14-24 forwards Bounded through Box);
+                           on the device every level is one more instantiation of the group traversal
+                           (out of line: code size and build time, not registers), so the depth is fixed
+                           — at twice what the reference's examples use */
   RPT_SHAPE_MONOMIAL = 5 /* src/shape/monomial_surface.rs:12-18  y = height*(x^2+z^2)^(exp/2),
                             x^2+z^2 <= 1; like the reference, intersection and normals are
                             only valid for exp = 4 (monomial_surface.rs:10): any other exp is

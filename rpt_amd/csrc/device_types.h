@@ -13,6 +13,11 @@
 namespace rptdev {
 
 constexpr int KD_MAX_STACK = 32; // deepest kd-tree the traversal stack holds
+// KdTree<Box<dyn Bounded>> inside KdTree<Box<dyn Bounded>> ...: a group may sit this many levels below a top-level group
+// (kernels/shapes.inc kd_leaf: one instantiation of the group traversal per level)
+#ifndef RPT_MAX_NEST
+#define RPT_MAX_NEST 3
+#endif
 constexpr int KD_LDS_LEVELS = 12;   // stack levels the persistent kernel keeps in LDS (rest: scratch)
 #ifndef RPT_KD_LDS_LEVELS_WF
 #define RPT_KD_LDS_LEVELS_WF 10

@@ -593,8 +593,12 @@ struct Flattener {
       }
       case RPT_SHAPE_GROUP: {
         // KdTree<Box<dyn Bounded>> forwards Bounded through Box (kdtree.rs:14-24), so a group can sit in a group;
-        // the device walks ONE inner level with its own stack (kernels/traversal.inc), deeper nesting is refused
-        if (nesting > 1) { err = "KdTree<Box<dyn Bounded>> nested more than two levels deep"; return RPTGPU_E_UNSUPPORTED_SHAPE; }
+        // the device instantiates the group traversal once per nesting level (kernels/shapes.inc kd_leaf, RPT_MAX_NEST):
+        // a group inside a group inside ... down to that level; the reference's recursion has no limit
+        if (nesting > RPT_MAX_NEST) {
+          err = "KdTree<Box<dyn Bounded>> nested more than " + std::to_string(RPT_MAX_NEST + 1) + " levels deep";
+          return RPTGPU_E_UNSUPPORTED_SHAPE;
+        }
         if (nesting > 0) fs.nested_mesh = true;
         if (!s.children && s.num_children) { err = "null children"; return RPTGPU_E_INVALID_ARGUMENT; }
         std::vector<rptdev::Inst> kids(s.num_children);

@@ -91,6 +91,37 @@ def nested_groups():
     return scene, camera
 
 
+def deep_nest():
+    """Groups four levels deep (the device's limit, RPT_MAX_NEST = 3 levels below a top-level group; the reference
+    recurses without one, kdtree.rs:14-24): every level placed by its own transform, a mesh, spheres, cubes and a monomial
+    surface at the bottom, siblings at every level, and a lamp that is itself nested four deep (KdTree::sample at every
+    level, kdtree.rs:138-143)."""
+    scene = Scene()
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0xAAAAAA))))
+    mesh = Mesh(scenes.knot_mesh(24, 6, seed=0xDEE9))
+    l3 = KdTree([mesh.scale((0.5, 0.5, 0.5)), sphere().scale((0.2, 0.2, 0.2)).translate((0.8, 0.0, 0.0)),
+                 cube().scale((0.3, 0.3, 0.3)).rotate_y(0.4).translate((-0.8, 0.1, 0.0)),
+                 monomial_surface(0.5, 4.0).scale((0.3, 0.3, 0.3)).translate((0.0, 0.6, 0.0))] +
+                [sphere().scale((0.07, 0.07, 0.07)).translate((-0.9 + 0.12 * i, -0.5, 0.3)) for i in range(16)])
+    l2 = KdTree([l3.rotate_y(0.3).translate((0.0, 0.0, 0.0)), l3.scale((0.6, 0.6, 0.6)).translate((1.5, 0.4, 0.2)),
+                 sphere().scale((0.25, 0.25, 0.25)).translate((-1.3, 0.0, 0.4))])
+    l1 = KdTree([l2.translate((-0.4, 0.0, 0.0)), l2.scale((0.5, 0.7, 0.5)).rotate_z(0.3).translate((0.3, 1.6, -0.5)),
+                 cube().scale((0.4, 0.4, 0.4)).translate((2.6, -0.6, 0.5))])
+    l0 = KdTree([l1.rotate_y(-0.2), l1.scale((0.4, 0.4, 0.4)).translate((-2.4, -0.3, 1.2)), sphere().translate((0.0, 0.0, -3.5))])
+    scene.add(Object(l0.translate((0.0, 0.2, 0.0))).material(Material.specular(hex_color(0x88AA66), 0.3)))
+    scene.add(Object(KdTree([l2.scale((0.5, 0.5, 0.5)).translate((2.2, 1.8, 1.0))])).material(Material.clear(1.5, 0.05)))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    scene.add(Light.Point((30.0, 30.0, 28.0), (2.0, 4.0, 4.5)))
+    b3 = KdTree([sphere().scale((0.12, 0.12, 0.12)).translate((0.3 * i, 0.0, 0.0)) for i in range(3)] +
+                [mesh.scale((0.15, 0.15, 0.15)).translate((0.45, 0.2, 0.0))])
+    b2 = KdTree([b3.translate((0.0, 0.0, 0.2)), cube().scale((0.2, 0.05, 0.2)).translate((1.2, 0.0, 0.0))])
+    b1 = KdTree([b2.rotate_y(0.5), b3.scale((0.8, 0.8, 0.8)).translate((-1.0, 0.1, 0.0))])
+    lamp = KdTree([b1.translate((-0.3, 3.2, 0.8)), sphere().scale((0.1, 0.1, 0.1)).translate((1.4, 3.1, 0.6))])
+    scene.add(Light.Object(Object(lamp).material(Material.light((1.0, 0.95, 0.85), 50.0))))
+    camera = Camera.look_at((0.6, 2.2, 6.8), (0.0, 0.4, 0.0), (0.0, 1.0, 0.0), 0.8)
+    return scene, camera
+
+
 def axis_sun():
     """Directional lights along the axes and in a coordinate plane over an UNTRANSFORMED deep mesh, a group of spheres and
     a plane: every shadow ray has one or two direction components that are exactly zero (the compact traversal's and the
@@ -185,6 +216,9 @@ def small(name):
     if name == "simple_video":
         s, c, d = scenes.simple_video(frame=7)
         return s, c, make_params(64, 48, 1, 4, seed=120)
+    if name == "deep_nest":
+        s, c = deep_nest()
+        return s, c, make_params(64, 40, 4, 4, seed=122)
     if name == "axis_sun":
         s, c = axis_sun()
         return s, c, make_params(64, 40, 4, 4, seed=121)
@@ -202,4 +236,4 @@ def small(name):
 HI_NAMES = ["cornell_hi", "coverage_hi"]
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
          "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots", "nested_groups",
-         "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video", "axis_sun"]
+         "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video", "axis_sun", "deep_nest"]

@@ -62,7 +62,7 @@ def test_unsupported_shapes_rejected_at_scene_create_without_gpu():
         rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_UNIMPLEMENTED_SAMPLE  # plane.rs:34-36 unimplemented!()
 
-    # a group inside a group is in the closed set (one level, kdtree.rs:14-24); a third level is not
+    # groups inside groups are in the closed set down to four levels (kdtree.rs:14-24; RPT_MAX_NEST); a fifth is not
     scene = rpt_amd.Scene()
     inner = rpt_amd.KdTree([rpt_amd.sphere().translate((0, 0, 0))])
     scene.add(rpt_amd.Object(rpt_amd.KdTree([inner, rpt_amd.sphere()])))
@@ -70,7 +70,13 @@ def test_unsupported_shapes_rejected_at_scene_create_without_gpu():
         rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_NO_DEVICE   # flattening succeeded; only the device is missing here
     scene = rpt_amd.Scene()
-    scene.add(rpt_amd.Object(rpt_amd.KdTree([rpt_amd.KdTree([inner, rpt_amd.cube()]), rpt_amd.sphere()])))
+    four = rpt_amd.KdTree([rpt_amd.KdTree([rpt_amd.KdTree([inner, rpt_amd.cube()]), rpt_amd.sphere()]), rpt_amd.cube()])
+    scene.add(rpt_amd.Object(four))
+    with pytest.raises(rpt_amd.RptGpuError) as e:
+        rpt_amd.GpuScene(scene)
+    assert e.value.code == _abi.RPTGPU_E_NO_DEVICE
+    scene = rpt_amd.Scene()
+    scene.add(rpt_amd.Object(rpt_amd.KdTree([four, rpt_amd.sphere()])))
     with pytest.raises(rpt_amd.RptGpuError) as e:
         rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
