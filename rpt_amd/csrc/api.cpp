@@ -734,6 +734,14 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       const rptdev::Inst& in = fs.insts[i];
       bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
       bool deep = tree && fs.tree_depth[in.tree] >= deep_depth;
+      // a kd-tree of kd-trees (fractal_teapots.rs) goes through the per-tree kernels whatever its own depth: the work
+      // is in the children's trees, and rpt_tree_trace (lean, four waves per SIMD, rays that miss the bounds never
+      // enter, lanes refilled) walks the nest 15 % faster than the object loop of rpt_extend: 84 -> 97 Msamples/s at
+      // 8 bounces.  Groups of spheres are the opposite case (C4 per-tree: 416 -> 278).  RPTGPU_NEST_PER_TREE=0: off
+      if (tree && !deep && in.kind == RPT_SHAPE_GROUP && fs.trees[in.tree].mesh_kids && fs.tree_depth[in.tree] >= 1) {
+        const char* e = std::getenv("RPTGPU_NEST_PER_TREE");
+        deep = !e || std::atoi(e) != 0;
+      }
       // rays entering a large tree are sorted by entry cell and octant first: neighbours in a wave then walk the same
       // nodes.  Measured with the VALU-bound traversal kernel of round 2: 100k-triangle mesh (66 MB of nodes + leaf
       // records) 144 -> 172 Msamples/s, 16k-triangle glass (17 MB) 469 -> 528, a 25k-triangle mesh under few bounces

@@ -88,7 +88,9 @@ struct alignas(16) Tree {
   uint32_t root_first; // that leaf's first entry in refs[] / lrec[]
   uint32_t split_range_ok; // regular, and every split value is 0 or has 2^-340 <= |v| < 2^399 (rpt_tree_trace's fast division)
   uint64_t sample_zone; // rand 0.8 UniformInt zone for Uniform::from(0..num_prims): u64::MAX - (2^64 - n) % n,
-  uint64_t _pad2;       // precomputed because a 64-bit modulo costs ~200 device instructions per light sample
+                        // precomputed because a 64-bit modulo costs ~200 device instructions per light sample
+  uint32_t mesh_kids;   // GROUP: some child is a MESH (a kd-tree of kd-trees): such an object is walked by the per-tree
+  uint32_t _pad2;       // kernels whatever its own depth (api.cpp)
   double qlo[3];        // MESH: origin and step of the LeafBox fixed-point grid (coordinate = qlo + q * qscale)
   double qscale[3];
 };

@@ -621,6 +621,8 @@ struct Flattener {
         // the children's boxes (Sphere / Cube / Mesh bounds through Transformed::bounding_box, shape.rs:153-176) contain
         // every point their intersect can return; the same filter as for triangles applies
         fill_leaf_boxes(fs, tr, -1, boxes, &kids);
+        for (const rptdev::Inst& k : kids)
+          if (k.kind == RPT_SHAPE_MESH) fs.trees[tr].mesh_kids = 1u;
         group_children.push_back({tr, std::move(kids)});
         in.tree = tr;
         const rptdev::Tree& t = fs.trees[tr];
