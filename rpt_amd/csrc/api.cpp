@@ -487,7 +487,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       if (std::getenv("RPTGPU_PRINT_LAUNCH"))
         std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp, "
                      "LDS %u B per wave (%u clamp-record levels)\n",
-                     flat ? (lay.obj_filter ? "KdFlat, object filter" : "KdFlat") : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds, flat ? lay.rec_levels : 0u);
+                     flat ? (lay.obj_filter ? "KdFlatF" : lay.n_tris ? "KdFlat" : "KdFlatG") : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds, flat ? lay.rec_levels : 0u);
       h->counters.alloc(4);
       h->pcounters.alloc(16);
       HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
@@ -836,17 +836,26 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         if (const char* e = std::getenv("RPTGPU_OBJECT_FILTER_MIN")) min_objects = std::atoi(e);
         const uint64_t every = fs.num_objects >= 64 ? ~0ull : (1ull << fs.num_objects) - 1ull;
         if (!lay.plane_cnt && min_objects > 0 && fs.num_objects >= min_objects && fs.obj_filter_ok &&
-            (fs.obj_always & every) != every &&
-            up16(off + (uint64_t)fs.num_objects * 6 * sizeof(double)) + REC_LEVEL <= WAVE_LDS) {
-          lay.obj_filter = 1;
-          lay.obj_always = fs.obj_always & every;
-          lay.off_obox = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 6 * sizeof(double));
-          h->obj_box.upload(fs.obj_lbox, h->stream);
-          std::vector<double> grid(fs.obj_grid, fs.obj_grid + 12);
-          h->obj_grid.upload(grid, h->stream);
-          HIP_TRY(hipStreamSynchronize(h->stream)); // `grid` dies with this block
-          lay.obj_box = h->obj_box.p;
-          lay.obj_grid = h->obj_grid.p;
+            (fs.obj_always & every) != every) {
+          // rpt_paths<KdFlatF> reads triangles from global memory (no plane table here, so `off` is final)
+          const FlatLayout keep = lay;
+          const uint64_t keep_off = off;
+          if (lay.n_tris) assign(false);
+          const uint64_t with_boxes = up16(off + (uint64_t)fs.num_objects * 6 * sizeof(double));
+          if (with_boxes + REC_LEVEL <= WAVE_LDS) {
+            lay.obj_filter = 1;
+            lay.obj_always = fs.obj_always & every;
+            lay.off_obox = (uint32_t)off; off = with_boxes;
+            h->obj_box.upload(fs.obj_lbox, h->stream);
+            std::vector<double> grid(fs.obj_grid, fs.obj_grid + 12);
+            h->obj_grid.upload(grid, h->stream);
+            HIP_TRY(hipStreamSynchronize(h->stream)); // `grid` dies with this block
+            lay.obj_box = h->obj_box.p;
+            lay.obj_grid = h->obj_grid.p;
+          } else {
+            lay = keep;
+            off = keep_off;
+          }
         }
       }
       lay.off_rec = (uint32_t)off;
