@@ -738,7 +738,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       // is in the children's trees, and rpt_tree_trace (lean, four waves per SIMD, rays that miss the bounds never
       // enter, lanes refilled) walks the nest 15 % faster than the object loop of rpt_extend: 84 -> 97 Msamples/s at
       // 8 bounces.  Groups of spheres are the opposite case (C4 per-tree: 416 -> 278).  RPTGPU_NEST_PER_TREE=0: off
-      if (tree && !deep && in.kind == RPT_SHAPE_GROUP && fs.trees[in.tree].mesh_kids && fs.tree_depth[in.tree] >= 1) {
+      if (tree && !deep && in.kind == RPT_SHAPE_GROUP && fs.trees[in.tree].mesh_kids) { // (also a single-leaf group: fractal_teapots' first two levels, 1 and 6 teapots)
         const char* e = std::getenv("RPTGPU_NEST_PER_TREE");
         deep = !e || std::atoi(e) != 0;
       }
@@ -757,8 +757,28 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         sort = h->sort_mode == 1 || (h->sort_mode < 0 && bytes >= h->sort_min_bytes);
       }
       h->sort_rays = h->sort_rays || sort;
-      h->obj_deep.push_back(deep ? (sort ? 2 : 1) : 0);
-      h->obj_tris.push_back(in.kind == RPT_SHAPE_MESH ? 1 : 0);
+      // obj_deep: 0 in-kernel; 1 per-tree; 2 per-tree with the ray sort; +4: the tree is irregular or the general form is
+      // forced at handle level — every ray of it goes through rpt_tree_general
+      h->obj_deep.push_back(deep ? (uint8_t)((sort ? 2 : 1) | ((!fs.trees[in.tree].regular) ? 4 : 0)) : 0);
+      // which traversal kernel of the per-tree pipeline: 1 rpt_tree_trace<TRIS>, 0 rpt_tree_trace over a group, 2 a group
+      // with mesh children whose two levels fit one traversal stack: rpt_nest_trace (RPTGPU_NEST_TRACE=0: the nested form)
+      uint8_t trace_kind = in.kind == RPT_SHAPE_MESH ? 1 : 0;
+      if (deep && in.kind == RPT_SHAPE_GROUP && fs.trees[in.tree].mesh_kids && fs.trees[in.tree].regular) {
+        const rptdev::Tree& tr = fs.trees[in.tree];
+        uint32_t inner_depth = 0;
+        bool ok = true; // rpt_nest_trace makes no calls: no group children, no irregular child trees
+        for (uint32_t k = 0; k < tr.num_prims; k++) {
+          const rptdev::Inst& kid = fs.insts[tr.prim_base + k];
+          if (kid.kind == RPT_SHAPE_GROUP) ok = false;
+          if (kid.kind == RPT_SHAPE_MESH) {
+            inner_depth = std::max(inner_depth, fs.tree_depth[kid.tree]);
+            ok = ok && fs.trees[kid.tree].regular;
+          }
+        }
+        const char* e = std::getenv("RPTGPU_NEST_TRACE");
+        if (ok && (!e || std::atoi(e) != 0) && fs.tree_depth[in.tree] + inner_depth + 2 <= (uint32_t)rptdev::KD_MAX_STACK) trace_kind = 2;
+      }
+      h->obj_tris.push_back(trace_kind);
       h->has_deep = h->has_deep || deep;
     }
     h->all_flat = true;

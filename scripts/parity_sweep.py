@@ -24,8 +24,10 @@ seed0 = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0xABCDE
 L, how = O.baseline_lib(native=True)
 print("oracle build: %s; %d spp on part %d of %d of the tiles, seeds from %#x" % (how, spp, part, parts, seed0))
 total = 0
-for name in ("sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "room23"):
+for name in ("sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "room23", "fractal_teapots"):
     scene, cam, cfg = scenes.SCENES[name]()
+    if name == "fractal_teapots":  # the example renders with 0 bounces; with 8, shadow and bounce rays walk the nests too
+        cfg = dict(cfg, max_bounces=8)
     W, H, B = cfg["width"], cfg["height"], cfg["max_bounces"]
     p = make_params(W, H, B, spp, seed=seed0 + len(name), tile=(32, 8), part=(part, parts))
     t0 = time.time()

@@ -236,7 +236,9 @@ def test_per_tree_queries_and_ray_sorting_do_not_change_the_image(name, sort, mo
 
 
 @pytest.mark.parametrize("knobs", [{"RPTGPU_LEAF_BOXES": "0"}, {"RPTGPU_SORT_RAYS": "1"},
-                                   {"RPTGPU_LEAF_BOXES": "0", "RPTGPU_SORT_RAYS": "1"}])
+                                   {"RPTGPU_LEAF_BOXES": "0", "RPTGPU_SORT_RAYS": "1"},
+                                   {"RPTGPU_NEST_TRACE": "0"},  # kd-trees of kd-trees the nested way (rpt_tree_trace<false>)
+                                   {"RPTGPU_NEST_TRACE": "0", "RPTGPU_LEAF_BOXES": "0"}])
 @pytest.mark.parametrize("name", ["dragon", "wine_glass", "coverage", "fractal_spheres", "fractal_teapots", "nested_groups", "deep_nest"])
 def test_leaf_box_filter_and_ray_sort_are_scheduling_only(name, knobs, monkeypatch):
     # the conservative box filter switched off, and the ray sort forced on, with every tree sent through the per-tree
