@@ -23,13 +23,14 @@ for item in $LIST; do
 done
 P=$PWD/rpt_amd/lib/librptgpu_prof.so
 if [ -f $P ]; then
-  for sc in "cornell 64" "room23 32" "dragon 16" "wine_glass 4" "fractal_spheres 4" "fractal_teapots 4"; do
+  for sc in "cornell 64" "room23 32" "dragon 16" "wine_glass 4" "fractal_spheres 4" "fractal_teapots 16 --bounces 8"; do
     set -- $sc
-    echo "## $1, $2 spp, 1 step (bench.py --scene $1 --steps 1 --warmup 0 --spp $2, librptgpu_prof.so = -DRPT_PROF build)" >> $O/phase_tables.txt
-    RPTGPU_LIB=$P RPTGPU_PRINT_PHASES=1 timeout 300 python bench.py --scene $1 --steps 1 --warmup 0 --spp $2 --no-cpu-baseline --no-live-pmc 2>&1 >/dev/null | grep "^prof" >> $O/phase_tables.txt
+    echo "## $1, $2 spp, 1 step (bench.py --scene $1 --steps 1 --warmup 0 --spp $2 $3 $4, librptgpu_prof.so = -DRPT_PROF build)" >> $O/phase_tables.txt
+    RPTGPU_LIB=$P RPTGPU_PRINT_PHASES=1 timeout 300 python bench.py --scene $1 --steps 1 --warmup 0 --spp $2 $3 $4 --no-cpu-baseline --no-live-pmc 2>&1 >/dev/null | grep "^prof" >> $O/phase_tables.txt
   done
 fi
 timeout 300 python bench.py --scene simple_video > $O/simple_video.json 2>/dev/null
+timeout 300 python bench.py --scene fractal_teapots --bounces 8 --spp 64 --steps 2 --warmup 1 --no-live-pmc > $O/fractal_teapots_b8.json 2>/dev/null
 python - <<'PY'
 import json
 d=json.load(open("gpurun_out/r03final/bench_default.json"))
