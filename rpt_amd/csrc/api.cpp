@@ -167,6 +167,7 @@ struct rptgpu_scene {
   StackSpill spill{};              // the per-tree traversal kernels' stack beyond the LDS levels (kernels.h)
   DevBuf<uint32_t> spill_node;
   DevBuf<double> spill_ts, spill_bmax;
+  DevBuf<double> tree_rays;        // [cap][8]: rpt_tree_enter's rows for the traversal kernels' refill
   // optional ray sort in front of the per-tree traversal (RPTGPU_SORT_RAYS)
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
   int sort_mode = -1;              // RPTGPU_SORT_RAYS: 0 never, 1 every deep tree, default: by footprint
@@ -349,7 +350,8 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
       uint32_t zeros_common = 0; // every shadow ray towards an axis-parallel directional light has a zero component
       for (const rptdev::Light& l : h->host_lights)
         if (l.kind == RPT_LIGHT_DIRECTIONAL && (l.vec[0] == 0.0 || l.vec[1] == 0.0 || l.vec[2] == 0.0)) zeros_common = 1;
-      h->spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads, zeros_common};
+      h->tree_rays.alloc(8 * cap); // one 64-byte row per position of a query: the rays that enter a tree (StackSpill::rays)
+      h->spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads, zeros_common, h->tree_rays.p};
     }
     if (h->sort_rays) {
       h->sort_kin.alloc(cap); h->sort_kout.alloc(cap); h->sort_vin.alloc(cap);
@@ -395,7 +397,7 @@ void print_prof(const KernelTable* kt, const char* what) {
 void release_workspace(rptgpu_scene* h) {
   h->ray.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->nrec.release(); h->rec.release();
   h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
-  h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release();
+  h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release(); h->tree_rays.release();
   h->ws_cap = 0; h->ws_bounces = 0;
 }
 
@@ -525,7 +527,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       if (!target) {
         const uint64_t nl = (uint64_t)std::max(1, h->dscene.num_lights);
         uint64_t per_path = 6 * 8 + 4 * 8 + 4 + 4 + 1 + (uint64_t)(p->max_bounces + 1) * rptdev::REC_FIELDS * 8 +
-                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + nl * (8 + 4) + (h->has_deep ? 12 + (h->sort_rays ? 12 + 16 : 0) : 0);
+                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + nl * (8 + 4) + (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0);
         uint64_t budget = h->ws_budget_bytes;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {

@@ -53,6 +53,11 @@ struct StackSpill {
   double* bmax;
   uint32_t threads;
   uint32_t zeros_common; // scene hint for launch_query: rays with a zero direction component are frequent (full grid for their kernel)
+  // [position in the query][8]: object-space origin and direction, record.time and stop distance of a ray that enters
+  // the tree — written by rpt_tree_enter, which has them in registers, as ONE 64-byte row; the traversal kernels' refill
+  // reads that row (and the slot from the query's queue) instead of gathering eight values from the path state's SoA
+  // arrays.  The tree's queues hold positions, not slots.
+  double* rays;
 };
 
 // accounting hook of launch_query: called with (ctx, kind, 0) before and (ctx, kind, 1) after the launches of
