@@ -49,5 +49,22 @@ int main() {
   rpthost::FlatScene fs2;
   rc = rpthost::flatten_scene(sc, fs2, err, nullptr);
   std::printf("with_group rc %d ok %d\n", rc, fs2.obj_filter_ok ? 1 : 0);
+  // the same rule one level down (fill_leaf_boxes for GROUP trees): a child sphere below 64 steps of the group's grid and
+  // a monomial surface carry the whole grid, their neighbours a box
+  {
+    std::vector<Shape> ring;
+    for (int i = 0; i < 20; i++) ring.push_back(sphere().scale({0.3, 0.3, 0.3}).translate({0.7 * i, 0.0, 0.0}));
+    ring.push_back(sphere().scale({1e-4, 1e-4, 1e-4}).translate({3.0, 1.0, 0.0}));   // child 20
+    ring.push_back(monomial_surface(0.5, 4.0).translate({5.0, 1.0, 0.0}));            // child 21
+    std::vector<RptObject> o2 = {{KdTree(ring).lower(arena), Material::diffuse({0.5, 0.5, 0.5}).lower()}};
+    RptScene s2{};
+    s2.objects = o2.data();
+    s2.num_objects = o2.size();
+    rpthost::FlatScene f3;
+    rc = rpthost::flatten_scene(s2, f3, err, nullptr);
+    std::printf("group rc %d trees %zu\n", rc, f3.trees.size());
+    const rptdev::Tree& t = f3.trees[0];
+    for (size_t j = t.ref_base; j < f3.refs.size(); j++) std::printf("ref child %u full %u\n", f3.refs[j], f3.lbox[j].w[3]);
+  }
   return 0;
 }

@@ -66,3 +66,9 @@ def test_object_filter_tables_exemptions_and_margins(tmp_path):
     assert 2e-3 / math.sqrt(3.0) < 64.0 * step.max() < 0.5 / math.sqrt(3.0)
     # a group among the top-level objects: no filter for that scene
     assert out[11].split() == ["with_group", "rc", "0", "ok", "0"]
+    # group children: the tiny sphere (child 20) and the monomial surface (child 21) are never filtered, the others are
+    assert out[12].split()[:3] == ["group", "rc", "0"]
+    refs = [(int(f[2]), int(f[4])) for f in (line.split() for line in out[13:]) if f and f[0] == "ref"]
+    assert len(refs) >= 22 and {c for c, _ in refs} == set(range(22))
+    for child, full in refs:
+        assert full == (1 if child in (20, 21) else 0), (child, full)
