@@ -159,6 +159,11 @@ struct rptgpu_scene {
   bool ext_shapes = false;       // scene has a shape only the *_ext kernel builds implement
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
+  // every per-tree object of the scene is one only by the kd-trees-of-kd-trees rule (shallow group, mesh children): for
+  // passes below nest_min_paths the object loop of rpt_extend is faster than five launches per object and query
+  // (fractal_teapots at 8 bounces, 3.8 M paths per pass: 60.7 against 56.9 Msamples/s; 7.7 M: 70.6 against 86.7)
+  bool deep_only_nests = false;
+  uint32_t nest_min_paths = 6u << 20; // RPTGPU_NEST_MIN_PATHS
   std::vector<rptdev::Light> host_lights; // (what launch decisions need of the lights)
   std::vector<uint32_t> cnt_host;  // the per-depth counters read back from the device
   bool has_deep = false;
@@ -574,7 +579,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         const uint32_t* queue = nullptr; // identity at depth 0
         uint32_t* next = h->queue_a.p;
         for (uint32_t depth = 0; depth <= p->max_bounces && n_active; depth++) {
-          const bool by_object = h->has_deep && !(p->flags & RPT_FLAG_GENERAL_TRAVERSAL);
+          // (a pass too small to pay for a nest's per-tree launches — see nest_min_paths — walks the scene in-kernel)
+          const bool by_object = h->has_deep && !(p->flags & RPT_FLAG_GENERAL_TRAVERSAL) &&
+                                 !(h->deep_only_nests && n_paths < h->nest_min_paths);
           const uint32_t trace_blocks = (uint32_t)std::max(1, h->num_cus * 4);
           { Bracket b(h, RPT_K_EXTEND, prof);
             if (by_object)
@@ -727,6 +734,8 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->num_cus = prop.multiProcessorCount;
     lap("device, stream, properties");
     h->prefer_wavefront = fs.max_tree_depth >= 3;
+    bool any_deep_by_depth = false;
+    if (const char* e = std::getenv("RPTGPU_NEST_MIN_PATHS")) h->nest_min_paths = (uint32_t)std::max(0, std::atoi(e));
     uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
     if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RPTGPU_RAYS_IN_KERNEL")) h->rays_in_kernel = std::atoi(e) != 0 ? 1 : 0;
@@ -740,10 +749,12 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       // is in the children's trees, and rpt_tree_trace (lean, four waves per SIMD, rays that miss the bounds never
       // enter, lanes refilled) walks the nest 15 % faster than the object loop of rpt_extend: 84 -> 97 Msamples/s at
       // 8 bounces.  Groups of spheres are the opposite case (C4 per-tree: 416 -> 278).  RPTGPU_NEST_PER_TREE=0: off
+      const bool deep_by_depth = deep;
       if (tree && !deep && in.kind == RPT_SHAPE_GROUP && fs.trees[in.tree].mesh_kids) { // (also a single-leaf group: fractal_teapots' first two levels, 1 and 6 teapots)
         const char* e = std::getenv("RPTGPU_NEST_PER_TREE");
         deep = !e || std::atoi(e) != 0;
       }
+      if (deep_by_depth) any_deep_by_depth = true;
       // rays entering a large tree are sorted by entry cell and octant first: neighbours in a wave then walk the same
       // nodes.  Measured with the VALU-bound traversal kernel of round 2: 100k-triangle mesh (66 MB of nodes + leaf
       // records) 144 -> 172 Msamples/s, 16k-triangle glass (17 MB) 469 -> 528, a 25k-triangle mesh under few bounces
@@ -783,6 +794,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       h->obj_tris.push_back(trace_kind);
       h->has_deep = h->has_deep || deep;
     }
+    h->deep_only_nests = h->has_deep && !any_deep_by_depth;
     h->all_flat = true;
     for (const rptdev::Tree& tr : fs.trees) h->all_flat = h->all_flat && tr.root_leaf != 0;
     if (h->all_flat) { // does the scene fit a wave's share of LDS (160 KB per CU / 8 waves)?

@@ -254,6 +254,20 @@ def test_leaf_box_filter_and_ray_sort_are_scheduling_only(name, knobs, monkeypat
     g.close()
 
 
+@pytest.mark.parametrize("name", ["fractal_teapots", "nested_groups"])
+def test_small_passes_of_nest_scenes_walk_in_kernel(name, monkeypatch):
+    # the library's default: a pass of fewer than 6 Mi paths of a scene whose only per-tree objects are kd-trees of
+    # kd-trees is walked by the object loop of rpt_extend / rpt_shadow_rays (conftest.py switches that off for the other
+    # tests) — the same image
+    monkeypatch.delenv("RPTGPU_NEST_MIN_PATHS", raising=False)
+    scene, cam, p = small_scenes.small(name)
+    g = GpuScene(scene, 0)
+    for flags in (_abi.RPT_FLAG_WAVEFRONT, 0):
+        img = g.render_batch(cam, make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=flags))
+        assert (img == load(name)["image"]).all(), (name, flags)
+    g.close()
+
+
 def test_c1_full_config_bit_equal_to_oracle(oracle):
     # BASELINE configs[0]: examples/sphere.rs, 960x540, 2 bounces, 100 spp — in full
     scene, cam, cfg = scenes.sphere_scene()
