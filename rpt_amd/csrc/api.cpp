@@ -482,14 +482,14 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       }
       const bool flat = h->all_flat && !h->dscene.force_general;
       FlatLayout lay = h->flat_layout;
-      lay.rec_levels = std::min(lay.rec_levels, p->max_bounces);
+      lay.rec_levels = RPT_FOLD_PIPE ? 0u : std::min(lay.rec_levels, p->max_bounces); // (the walker's records live in global memory)
       if (const char* e = std::getenv("RPTGPU_FLAT_REC_LEVELS")) lay.rec_levels = std::min(lay.rec_levels, (uint32_t)std::max(0, std::atoi(e)));
       const uint32_t flat_lds = flat ? lay.off_rec + lay.rec_levels * 4096u : 0u;
       int per_cu = kt->paths_max_blocks_per_cu(flat, flat_lds);
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
       nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
       uint64_t nthreads = (uint64_t)nblocks * 64;
-      h->prec.alloc(std::max<uint64_t>(1, (uint64_t)p->max_bounces) * rptdev::REC_FIELDS * nthreads);
+      h->prec.alloc((uint64_t)rpt_fold_ring_slots(p->max_bounces) * rptdev::REC_FIELDS * nthreads);
       h->lbuf.alloc(std::max<uint64_t>(1, (uint64_t)spp_l * 3 * npix));
       if (std::getenv("RPTGPU_PRINT_LAUNCH"))
         std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp, "

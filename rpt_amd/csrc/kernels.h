@@ -10,6 +10,14 @@
 #define RPT_FLAT_RUN 6
 #endif
 
+// rpt_paths folds the nested clamp with a per-lane walker, one level per loop iteration (kernels/paths.inc); 0 = the
+// fold loop on the spot, as in rounds 1-3 (A/B builds)
+#ifndef RPT_FOLD_PIPE
+#define RPT_FOLD_PIPE 1
+#endif
+// slots (of REC_FIELDS doubles) per thread of the persistent path kernel's record ring (kernels/paths.inc says why)
+static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * max_bounces + 2u; }
+
 // layout of the flat path kernel's dynamic LDS (byte offsets; lrec at 0), see kernels.inc
 struct FlatLayout {
   uint32_t off_tris, off_refs, off_mat, off_leaf, off_rec;
