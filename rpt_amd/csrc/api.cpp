@@ -481,10 +481,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         while ((n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk)) > item_limit) chunk++;
       }
       const bool flat = h->all_flat && !h->dscene.force_general;
-      FlatLayout lay = h->flat_layout;
-      lay.rec_levels = RPT_FOLD_PIPE ? 0u : std::min(lay.rec_levels, p->max_bounces); // (the walker's records live in global memory)
-      if (const char* e = std::getenv("RPTGPU_FLAT_REC_LEVELS")) lay.rec_levels = std::min(lay.rec_levels, (uint32_t)std::max(0, std::atoi(e)));
-      const uint32_t flat_lds = flat ? lay.off_rec + lay.rec_levels * 4096u : 0u;
+      FlatLayout lay = flat ? h->flat_layout : FlatLayout{};
+      const uint32_t flat_lds = lay.off_end;
       int per_cu = kt->paths_max_blocks_per_cu(flat, flat_lds);
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
       nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
@@ -493,8 +491,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       h->lbuf.alloc(std::max<uint64_t>(1, (uint64_t)spp_l * 3 * npix));
       if (std::getenv("RPTGPU_PRINT_LAUNCH"))
         std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp, "
-                     "LDS %u B per wave (%u clamp-record levels)\n",
-                     flat ? (lay.obj_filter ? "KdFlatF" : lay.n_tris ? "KdFlat" : "KdFlatG") : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds, flat ? lay.rec_levels : 0u);
+                     "dynamic LDS %u B per wave (the flat scene's tables)\n",
+                     flat ? (lay.obj_filter ? "KdFlatF" : lay.n_tris ? "KdFlat" : "KdFlatG") : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds);
       h->counters.alloc(4);
       h->pcounters.alloc(16);
       HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
@@ -509,7 +507,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
         { Bracket b(h, RPT_K_PATHS, prof);
           kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk,
-                    (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, flat ? &lay : nullptr, flat_lds);
+                    (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, lay, flat, flat_lds);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
       }
@@ -798,7 +796,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->all_flat = true;
     for (const rptdev::Tree& tr : fs.trees) h->all_flat = h->all_flat && tr.root_leaf != 0;
     if (h->all_flat) { // does the scene fit a wave's share of LDS (160 KB per CU / 8 waves)?
-      constexpr uint32_t WAVE_LDS = 20480, REC_LEVEL = 4096; // 64 lanes x 8 doubles per clamp-record level
+      constexpr uint32_t WAVE_LDS = RPT_PATHS_WAVE_LDS - RPT_PATHS_WALKER_LDS; // the wave's share less the fold walker's state
       auto up16 = [](uint64_t v) { return (v + 15) & ~15ull; };
       uint64_t off = 0;
       FlatLayout lay{};
@@ -815,7 +813,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         lay.off_leaf = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 16);
       };
       assign(true);
-      if (off + 12 * 64 * sizeof(double) + REC_LEVEL > WAVE_LDS || std::getenv("RPTGPU_FLAT_TRIS_GLOBAL")) assign(false); // (room for the plane table and one record level)
+      if (off + 12 * 64 * sizeof(double) > WAVE_LDS || std::getenv("RPTGPU_FLAT_TRIS_GLOBAL")) assign(false); // (room for the plane table)
       // shared slab quotients: distinct plane coordinates per axis over the untransformed meshes (bitwise
       // distinct: -0.0 and 0.0 give differently signed zeros), at most 4 per axis or the feature stays off
       std::vector<double> planes(12, 0.0);
@@ -857,7 +855,19 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
           in.plane_use = std::min<uint32_t>((uint32_t)RPT_FLAT_RUN, 1u + next);
         }
         lay.plane_cnt = cnt[0] | (cnt[1] << 4) | (cnt[2] << 8);
-        lay.off_qtab = (uint32_t)off; off = up16(off + 12 * 64 * sizeof(double));
+        // the table's slots are packed (x planes, then y, then z): plane_idx goes from axis * 4 + j to that numbering
+        const uint32_t base[3] = {0u, cnt[0], cnt[0] + cnt[1]};
+        for (int i = 0; i < fs.num_objects; i++) {
+          rptdev::Inst& in = fs.insts[i];
+          if (!in.plane_use) continue;
+          uint32_t packed = 0;
+          for (int k = 0; k < 6; k++) {
+            const uint32_t sl = (in.plane_idx >> (4 * k)) & 15u;
+            packed |= (base[sl >> 2] + (sl & 3u)) << (4 * k);
+          }
+          in.plane_idx = packed;
+        }
+        lay.off_qtab = (uint32_t)off; off = up16(off + (uint64_t)(cnt[0] + cnt[1] + cnt[2]) * 64 * sizeof(double));
         h->plane_vals.upload(planes, h->stream);
         HIP_TRY(hipStreamSynchronize(h->stream)); // `planes` dies with this block
         lay.plane_vals = h->plane_vals.p;
@@ -876,7 +886,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
           const uint64_t keep_off = off;
           if (lay.n_tris) assign(false);
           const uint64_t with_boxes = up16(off + (uint64_t)fs.num_objects * 6 * sizeof(double));
-          if (with_boxes + REC_LEVEL <= WAVE_LDS) {
+          if (with_boxes <= WAVE_LDS) {
             lay.obj_filter = 1;
             lay.obj_always = fs.obj_always & every;
             lay.off_obox = (uint32_t)off; off = with_boxes;
@@ -892,11 +902,10 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
           }
         }
       }
-      lay.off_rec = (uint32_t)off;
+      lay.off_end = (uint32_t)off;
       if (off > WAVE_LDS) {
         h->all_flat = false;
       } else {
-        lay.rec_levels = (uint32_t)((WAVE_LDS - off) / REC_LEVEL);
         h->flat_layout = lay;
       }
     }

@@ -10,21 +10,19 @@
 #define RPT_FLAT_RUN 6
 #endif
 
-// rpt_paths folds the nested clamp with a per-lane walker, one level per loop iteration (kernels/paths.inc); 0 = the
-// fold loop on the spot, as in rounds 1-3 (A/B builds)
-#ifndef RPT_FOLD_PIPE
-#define RPT_FOLD_PIPE 1
-#endif
 // slots (of REC_FIELDS doubles) per thread of the persistent path kernel's record ring (kernels/paths.inc says why)
 static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * max_bounces + 2u; }
+// LDS of one wave of rpt_paths: 160 KB per CU / (2 waves per SIMD x 4 SIMDs); the fold walker's static share of it
+#define RPT_PATHS_WAVE_LDS 20480u
+#define RPT_PATHS_WALKER_LDS 2560u
 
 // layout of the flat path kernel's dynamic LDS (byte offsets; lrec at 0), see kernels.inc
 struct FlatLayout {
-  uint32_t off_tris, off_refs, off_mat, off_leaf, off_rec;
-  uint32_t rec_levels;
+  uint32_t off_tris, off_refs, off_mat, off_leaf;
+  uint32_t off_end;              // end of the scene's tables (0 for scenes that are not flat)
   uint32_t n_refs, n_tris;
   // distinct bounding-plane coordinates of the untransformed meshes, at most 4 per axis: the quotient
-  // (value - o) / d of each is computed ONCE per ray into off_qtab ([12 slots][64 lanes] doubles) and shared
+  // (value - o) / d of each is computed ONCE per ray into off_qtab ([distinct planes][64 lanes] doubles) and shared
   // by every mesh whose box uses that plane (the walls of C2 have 30 faces on 6 distinct planes)
   uint32_t off_qtab, plane_cnt;  // plane_cnt: 4 bits per axis; 0 = feature off
   const double* plane_vals;      // [3][4] in device memory
@@ -90,10 +88,10 @@ struct KernelTable {
   void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32);
   void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
   // persistent per-pixel kernel: resident 64-thread blocks per CU, and the launch
-  int (*paths_max_blocks_per_cu)(bool flat, uint32_t flat_lds_bytes);
+  int (*paths_max_blocks_per_cu)(bool flat, uint32_t lds_bytes);
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
-                uint32_t chunk, uint32_t n_items, uint32_t nblocks, const FlatLayout* flat, uint32_t flat_lds_bytes);
+                uint32_t chunk, uint32_t n_items, uint32_t nblocks, const FlatLayout& lay, bool flat, uint32_t lds_bytes);
   // pixel sums of a launch's samples, in sample order
   void (*sum_samples)(hipStream_t, const rptdev::Frame&, const double* lbuf, uint32_t spp, bool first);
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run

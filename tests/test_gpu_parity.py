@@ -332,9 +332,8 @@ def test_persistent_work_item_size_and_launch_split_do_not_change_the_image(buil
         scene, cam, p, g = built(name)
         pp = make_params(p.width, p.height, p.max_bounces, 7, p.exposure_value, p.seed, flags=_abi.RPT_FLAG_PERSISTENT)
         ref = g.render_batch(cam, pp)
-        for chunk, spp_cap, rec_levels in ((1, 7, 0), (3, 7, 1), (16, 2, 2), (2, 3, 3), (5, 1, 99)):
+        for chunk, spp_cap in ((1, 7), (3, 7), (16, 2), (2, 3), (5, 1)):
             monkeypatch.setenv("RPTGPU_PATHS_CHUNK", str(chunk))
-            monkeypatch.setenv("RPTGPU_FLAT_REC_LEVELS", str(rec_levels))  # clamp-record levels kept in LDS
             monkeypatch.setenv("RPTGPU_LBUF_BYTES", str(p.width * p.height * 24 * spp_cap))
             g2 = GpuScene(scene, 0)
             pq = make_params(p.width, p.height, p.max_bounces, 7, p.exposure_value, p.seed,
