@@ -7,7 +7,7 @@ no FMA contraction).  The timed region is what `Renderer::sample` covers (SURVEY
 through the last bounce, the reduce over ranks, and the write of the W*H mean colours into HOST memory
 (rank 0); scene construction (kd build + upload) is outside it and reported as `scene_create_ms` /
 `wall_clock_per_frame_ms`.  With N GPUs rank r renders the tiles tile_id % N == r of the SAME frame
-(strong scaling) and the f32 framebuffers are summed to rank 0 by one RCCL reduce per step.
+(strong scaling) and rank 0 gathers the f32 pixels each rank owns, one RCCL send / receive group per step.
 
     python bench.py                      # 1 GPU: the headline (C2) + the other BASELINE configs + live counters
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -16,9 +16,9 @@ through the last bounce, the reduce over ranks, and the write of the W*H mean co
     python bench.py --scene simple_video             # scene rebuilt per frame (examples/simple_video.rs): frames/s
 
 The default 1-GPU run prints ONE JSON line.  Besides the headline it carries
-  * `other_configs`: BASELINE configs[2-4] (dragon-class mesh, fractal spheres, wine glass) at their own frame
-    sizes and a reduced spp (cost per sample does not depend on spp), 2 steps + 1 warm-up each, each with its
-    own roofline object and CPU baseline;
+  * `other_configs`: BASELINE configs[2-4] (dragon-class mesh, fractal spheres, wine glass — mesh and glass-spheres
+    variants) at their own frame sizes and >= 16 spp per step (cost per sample does not depend on spp), 3 steps +
+    1 warm-up each, each with its own roofline object and CPU baseline (>= 16 spp, median of 3 repetitions);
   * `roofline` objects whose counter fields (VALU busy, lanes active per VALU instruction, HBM bytes, L2 requests)
     are measured IN THIS RUN: bench.py re-runs one step of each workload under `rocprofv3 --pmc ... --kernel-trace`
     in a child process (no torch, ~10 s per pass) and reads the counters back.  If rocprofv3 is not usable the
@@ -49,7 +49,11 @@ ENV = 4 * 32
 FB = 24
 
 # the other BASELINE configs in the default run: (scene, spp per step).  Frame size and bounces are the config's own.
-OTHER_CONFIGS = (("dragon", 32), ("fractal_spheres", 8), ("wine_glass", 8))
+# (>= 16 spp, 3 steps + 1 warm-up each; the glass SPHERES variant of C5 — examples/glass.rs — renders 64 spp per step:
+# its step would otherwise be 30 ms)
+OTHER_CONFIGS = (("dragon", 32), ("fractal_spheres", 16), ("wine_glass", 16), ("glass", 64))
+OTHER_STEPS, OTHER_WARMUP = 3, 1
+CPU_MIN_SPP, CPU_REPS = 16, 3
 PMC_A = "FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
 PMC_B = "WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM"
 PMC_C = "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
@@ -270,7 +274,10 @@ def accounting(wl, st):
 
 
 def cpu_baseline(wl, osc, budget_s, cpu_spp=None):
-    """the oracle (uninstrumented -march=native build) on this box's host cores, on a sample sized for ~budget_s"""
+    """the oracle (uninstrumented -march=native build) on this box's host cores: BASELINE.md §2 — the config's frame
+    size and bounce count at >= 16 spp, CPU_REPS repetitions of about budget_s seconds each, the MEDIAN reported.  A
+    whole frame at 16 spp takes minutes on the slower configs, so a repetition renders 1/k of the interleaved 32x8
+    tiles (a regular sample of the whole frame: cost per sample as in the full frame), k sized for budget_s."""
     from oracle import oracle_ffi as O
     from rpt_amd import make_params
     ncores, raw = host_cpus()
@@ -281,29 +288,40 @@ def cpu_baseline(wl, osc, budget_s, cpu_spp=None):
     t1 = time.perf_counter()
     fast.render(wl.camera, pcal, threads=ncores)
     rate = (W * H / 8.0) / max(1e-6, time.perf_counter() - t1)
-    want = rate * budget_s / (W * H)
-    part = (0, 1)
-    if want < 1.0:  # not even one spp of the whole frame fits: take 1 spp on a fraction of the tiles
-        part = (0, int(min(64, max(2, round(1.0 / max(want, 1e-3))))))
-    spp = cpu_spp or int(min(64, max(1, round(want))))
-    pcpu = make_params(W, H, B, spp, seed=0x52505447, tile=(32, 8), part=part)
-    t1 = time.perf_counter()
-    fast.render(wl.camera, pcpu, threads=ncores)
-    dt = time.perf_counter() - t1
-    n_samples = W * H * spp / part[1]
-    cpu = {"value": n_samples / dt / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
-           "sample": "%s %dx%d, %d bounces, %d spp%s (%.1f s wall): C++ restatement of rpt's rayon path (oracle/, %s), one task "
-                     "per row claimed dynamically by %d std::threads on %s (%d logical CPUs)"
-                     % (wl.name, W, H, B, spp, "" if part[1] == 1 else " on 1/%d of the 32x8 tiles" % part[1], dt, how, ncores,
-                        cpu_model(), raw)}
-    if osc is not None and budget_s >= 8:  # the instrumented checker build on a quarter of that sample, for the record
-        pins = make_params(W, H, B, max(1, spp // 4), seed=0x52505447, tile=(32, 8), part=part)
+    spp = max(CPU_MIN_SPP, cpu_spp or 0)
+    whole = W * H * spp / rate                      # seconds for the whole frame at spp
+    k = int(min(256, max(1, round(whole / budget_s))))
+    pcpu = make_params(W, H, B, spp, seed=0x52505447, tile=(32, 8), part=(0, k))
+    n_pix = W * H if k == 1 else int(count_part_pixels(W, H, k))
+    rates, walls = [], []
+    for rep in range(CPU_REPS):
         t1 = time.perf_counter()
-        osc.render(wl.camera, pins, threads=ncores)
+        fast.render(wl.camera, pcpu, threads=ncores)
+        dt = time.perf_counter() - t1
+        walls.append(dt)
+        rates.append(n_pix * spp / dt / 1e6)
+    med = sorted(rates)[len(rates) // 2]
+    cpu = {"value": med, "unit": "Msamples/s", "cores": ncores, "kind": "port", "repetitions": CPU_REPS,
+           "all_repetitions": rates,
+           "sample": "%s %dx%d, %d bounces, %d spp%s, median of %d repetitions (%.1f s wall each): C++ restatement of rpt's rayon "
+                     "path (oracle/, %s), one task per row claimed dynamically by %d std::threads on %s (%d logical CPUs)"
+                     % (wl.name, W, H, B, spp, "" if k == 1 else " on 1/%d of the interleaved 32x8 tiles" % k, CPU_REPS,
+                        sorted(walls)[len(walls) // 2], how, ncores, cpu_model(), raw)}
+    if osc is not None and budget_s >= 4:  # the instrumented checker build on the same sample, once, for the record
+        t1 = time.perf_counter()
+        osc.render(wl.camera, pcpu, threads=ncores)
         dti = time.perf_counter() - t1
-        cpu["instrumented_checker_build"] = {"value": W * H * pins.iterations / part[1] / dti / 1e6, "unit": "Msamples/s",
+        cpu["instrumented_checker_build"] = {"value": n_pix * spp / dti / 1e6, "unit": "Msamples/s",
                                              "note": "liboracle.so with visit counters compiled in (x86-64-v3)"}
     return cpu
+
+
+def count_part_pixels(W, H, k, tile=(32, 8)):
+    """pixels of the tiles with tile_id % k == 0"""
+    import numpy as np
+    tiles_x = (W + tile[0] - 1) // tile[0]
+    ys, xs = np.mgrid[0:H, 0:W]
+    return int((((ys // tile[1]) * tiles_x + xs // tile[0]) % k == 0).sum())
 
 
 def kernel_table(wl, st, bytes_k):
@@ -339,8 +357,12 @@ def roofline_object(wl, st, kernels, dominant, kern_n, bytes_k, pmc, pmc_note, p
     acc = kernels[dominant]["accounting_GBs"]
     roof = {"bound": "valu", "kernel": dominant, "unit": "Tlane-slot/s (f64 VALU: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2)",
             "peak": VALU_F64_PEAK_TLANES, "achieved": None, "frac": None, "traffic": None,
+            "frac_is": "VALU busy x lanes active / 64 of the dominant kernel (SQ counters of this run): the share of the f64 "
+                       "lane slots that did work.  NOT bytes / HBM peak — that figure is accounting_frac below",
             "accounting_GBs": acc, "accounting_frac": (acc / HBM_PEAK_GBS) if acc else None,
-            "accounting_is": "SURVEY §8d algorithmic bytes of the REFERENCE traversal / launch time / 8 TB/s (may exceed 1)",
+            "accounting_is": "SURVEY §8d: algorithmic bytes of the REFERENCE traversal x units / launch time / 8 TB/s.  The bytes "
+                             "are served from registers, LDS and L2 (hbm_frac is the measured HBM share) and partly never "
+                             "touched (leaf-box filter, untraced zero-contribution shadow rays): exceeds 1 when cache-served",
             "alg_bytes_per_sample": bytes_k["rpt_paths"] / rank_samples if rank_samples else None,
             "kernels": kernels}
     k, src = None, None
@@ -440,7 +462,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="headline only")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run a step under rocprofv3 for the counter fields")
-    ap.add_argument("--cpu-spp", type=int, default=None, help="spp of the CPU-baseline sample (default: ~12 s of CPU work)")
+    ap.add_argument("--cpu-spp", type=int, default=None, help="spp of the CPU-baseline sample (default and minimum: 16)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 saves the last step's reduced f32 frame (.npy)")
     ap.add_argument("--fixed-samples", action="store_true", help="every step renders the same samples (tests)")
     ap.add_argument("--emulate-part-of", type=int, default=0, metavar="N",
@@ -584,6 +606,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = gpu.stats()
+    # what each rank spent where (HIP events inside rptgpu_render_batch_reduce), and the rays it traced
+    mine = {"rank": rank, "render_ms_per_step": st.reduce_render_ms / max(1, st.reduce_calls),
+            "collective_ms_per_step": st.reduce_collective_ms / max(1, st.reduce_calls),
+            "copy_ms_per_step": st.reduce_copy_ms / max(1, st.reduce_calls),
+            "extend_rays": int(st.extend_rays), "shadow_rays": int(st.shadow_rays), "shadow_rays_traced": int(st.shadow_rays_traced),
+            "scene_create_ms": wl.scene_create_ms}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    rays_traced = float(sum(r["extend_rays"] + r["shadow_rays_traced"] for r in per_rank))
+    rays_reference = float(sum(r["extend_rays"] + r["shadow_rays"] for r in per_rank))
 
     if rank == 0 and args.dump_frame:
         np.save(args.dump_frame, host_frame.numpy())
@@ -602,7 +636,7 @@ def main():
         roofline = roofline_object(wl, st, kernels, dominant, kern_n, bytes_k, pmc, pmc_note, spp)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(wl, osc, 12.0, args.cpu_spp)
+            cpu = cpu_baseline(wl, osc, 6.0, args.cpu_spp)
 
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -614,11 +648,18 @@ def main():
                        "precision_mode": "strict",
                        "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")),
                        "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
-                       "collective": ("ncclReduce(sum, f32 framebuffer) to rank 0 inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else ("torch.distributed reduce (the library's communicator could not be set up: %s)" % collective_note if collective_note else "torch.distributed reduce (gloo stand-in)")) if world > 1 else "none",
-                       "timed_region": "render + reduce + D2H of the f32 frame to pinned host memory on rank 0",
-                       "rays_per_s": (st.extend_rays + st.shadow_rays) / elapsed * (world if world > 1 else 1),
-                       "rays_are": "the rays the REFERENCE casts for these samples (closest-hit + one shadow ray per hit and light); "
-                                   "shadow rays that can only add zero are not traced here",
+                       "collective": (("ncclReduce(sum, f32 framebuffer) to rank 0" if os.environ.get("RPTGPU_COLLECTIVE") == "reduce" else
+                                       "gather of the pixels each rank owns (ncclSend / ncclRecv, W*H*12/N bytes per rank) to rank 0")
+                                      + " inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else ("torch.distributed reduce (the library's communicator could not be set up: %s)" % collective_note if collective_note else "torch.distributed reduce (gloo stand-in)")) if world > 1 else "none",
+                       "timed_region": "render (f64 arithmetic) + gather of the f32 means over the ranks + D2H of the f32 frame to pinned "
+                                       "host memory on rank 0 (rptgpu_render_batch_reduce; the f64 seam rptgpu_render_batch is what the "
+                                       "parity tests compare, the same kernels)",
+                       "rays_per_s": rays_traced / elapsed,
+                       "rays_are": "rays actually traced, from the kernels' own counters: closest-hit rays + the shadow rays "
+                                   "that were traversed (summed over the ranks)",
+                       "reference_rays_per_s": rays_reference / elapsed,
+                       "reference_rays_are": "the rays the REFERENCE casts for these samples: closest-hit + one shadow ray per hit "
+                                             "and non-ambient light, including the ones whose light can only add exactly zero",
                        "scene_create_ms": wl.scene_create_ms,
                        "scene_create_is": "flatten + kd build + upload of the FIRST scene of the process (includes HIP "
                                           "initialisation when nothing else has touched the GPU); scene_create_warm_ms = the "
@@ -627,6 +668,9 @@ def main():
                        "wall_clock_per_frame_ms": (wl.scene_create_warm_ms or wl.scene_create_ms) + elapsed / args.steps * 1e3},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "per_rank": per_rank,
+            "per_rank_is": "HIP-event time per step inside rptgpu_render_batch_reduce on each rank: its own tiles / the gather "
+                           "(includes waiting for the slowest rank) / on rank 0 the assembly of the frame and its D2H",
         }
         # ---- the other BASELINE configs on the same clock (1 GPU, default invocation only)
         if default_run and world == 1 and not args.no_other_configs:
@@ -636,7 +680,7 @@ def main():
                 try:
                     o = Workload(name, args, 0, 1, local_rank, backend, spp=ospp, is_headline=False)
                     buf = np.empty(o.W * o.H * 3, dtype=np.float32)
-                    osteps, owarm = 2, 1
+                    osteps, owarm = OTHER_STEPS, OTHER_WARMUP
                     for _ in range(owarm):
                         o.gpu.render_batch_reduce(o.camera, o.params(), root=0, out=buf)
                         o.step_no += 1
@@ -655,12 +699,13 @@ def main():
                     opmc, onote = (None, "--no-live-pmc") if args.no_live_pmc else live_pmc(name, ospp, (PMC_A,))
                     oroof = roofline_object(o, ost, ok, odom, okn, ob, opmc, onote, ospp)
                     oroof["kernels"] = {k: {"launches": v["launches"], "avg_ms": v["avg_ms"], "total_ms": v["total_ms"]} for k, v in ok.items()}
-                    ocpu = None if args.no_cpu_baseline else cpu_baseline(o, None, 4.0)
+                    ocpu = None if args.no_cpu_baseline else cpu_baseline(o, None, 4.0, args.cpu_spp)
                     others.append({"workload": "%s %dx%d, %d bounces, %d spp per step" % (name, o.W, o.H, o.B, ospp),
                                    "value": float(o.W) * o.H * ospp * osteps / dt / 1e6, "unit": "Msamples/s",
                                    "ms_per_step": dt / osteps * 1e3, "steps": osteps, "warmup": owarm, "spp": ospp,
                                    "scene_create_ms": o.scene_create_ms,
-                                   "rays_per_s": (ost.extend_rays + ost.shadow_rays) / dt,
+                                   "rays_per_s": (ost.extend_rays + ost.shadow_rays_traced) / dt,
+                                   "reference_rays_per_s": (ost.extend_rays + ost.shadow_rays) / dt,
                                    "roofline": oroof, "cpu_baseline": ocpu,
                                    "wall_s_of_this_entry": None})
                 except Exception as e:  # one config must not cost the bench line

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPTGPU_ABI_VERSION 4
+#define RPTGPU_ABI_VERSION 5
 
 /* ---- error codes (replace the reference's panics: buffer.rs:26,33,89, plane.rs:35) ---- */
 enum {
@@ -233,6 +233,11 @@ typedef struct RptStats {
                             (bsdf = 0 below an opaque surface, a light sample facing away) needs no ray  */
   uint64_t samples;      /* camera paths started                                             */
   double total_ms;       /* wall time inside rptgpu_render_batch* (host clock)                */
+  /* rptgpu_render_batch_reduce since the last reset (ABI v5), HIP events on the library's stream: */
+  uint64_t reduce_calls;
+  double reduce_render_ms;     /* this rank's own tiles                                         */
+  double reduce_collective_ms; /* the gather (or reduce) over the ranks: includes waiting for the slowest one */
+  double reduce_copy_ms;       /* root: assembling the frame and its copy to host memory        */
 } RptStats;
 
 typedef struct rptgpu_scene rptgpu_scene; /* opaque */
@@ -277,16 +282,33 @@ int rptgpu_render_batch_device(rptgpu_scene* h, const RptCamera* camera,
  *   every rank:  rptgpu_comm_init(h, rank, world, id);
  *   per batch:   rptgpu_render_batch_reduce(h, camera, params, root, out_rgb32_on_root)
  * rptgpu_render_batch_reduce replaces the body of Renderer::sample on every rank: it renders this
- * rank's tiles (params->tile_*, part_* are overridden: 32x8 tiles, part = rank of world), reduces the
- * f32 frames to `root` with ncclReduce(sum) on the library's stream over xGMI, and on `root` writes the
- * width*height*3 f32 means to host memory (out_rgb32 may be NULL on other ranks).  Synchronous.
- * With no communicator attached (world = 1) it is a plain single-GPU render into out_rgb32. */
+ * rank's tiles (params->tile_*, part_* are overridden: 32x8 tiles, part = rank of world), brings the f32
+ * means to `root` over xGMI on the library's stream, and on `root` writes the width*height*3 f32 means to
+ * host memory (out_rgb32 may be NULL on other ranks).  Synchronous.  The exchange is a GATHER: every rank
+ * sends only the pixels it owns (width*height*3*4 / world bytes, ncclSend / ncclRecv in one group), the
+ * root puts them in place — the tiles are disjoint, so nothing is added and the frame is the one a single
+ * GPU renders, bit for bit.  RPTGPU_COLLECTIVE=reduce selects ncclReduce(sum) of zero-filled full frames
+ * instead (8x the bytes at 8 ranks; the same frame, since every pixel is non-zero on one rank only).
+ * With no communicator attached (world = 1) it is a plain single-GPU render into out_rgb32.
+ * Failure: the call waits for the stream by polling it together with ncclCommGetAsyncError, at most
+ * RPTGPU_COMM_TIMEOUT_S seconds (default 300) per batch.  A rank that fails locally (HIP error, out of
+ * memory), sees an asynchronous RCCL error or times out aborts its communicator (ncclCommAbort) and
+ * returns RPTGPU_E_COMM / its own error; its peers then run into their time-out or an RCCL error and do
+ * the same.  After that every further rptgpu_render_batch_reduce on the handle returns RPTGPU_E_COMM until
+ * rptgpu_comm_destroy + rptgpu_comm_init.  Argument errors that every rank makes alike (bad params) are
+ * returned before anything is enqueued and leave the communicator alone. */
 #define RPTGPU_UNIQUE_ID_BYTES 128
 int rptgpu_comm_unique_id(uint8_t out_id[RPTGPU_UNIQUE_ID_BYTES]);
 int rptgpu_comm_init(rptgpu_scene* h, int rank, int world, const uint8_t id[RPTGPU_UNIQUE_ID_BYTES]);
 int rptgpu_comm_destroy(rptgpu_scene* h);
 int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params,
                                int root, float* out_rgb32 /* width*height*3 f32, host, on root */);
+/* Diagnostics: the frame as `world` ranks would produce it, on this one GPU and without a communicator — every
+ * rank's part rendered in turn into the root's receive buffer (packed, as ncclSend would deliver it) and placed by
+ * the root's pixel lists: the gather of rptgpu_render_batch_reduce minus the wire.  Must equal the frame of a plain
+ * render bit for bit (tests; a box with one GPU cannot run RCCL across two ranks). */
+int rptgpu_render_batch_emulate_ranks(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params,
+                                      int world, float* out_rgb32 /* width*height*3 f32, host */);
 
 /* ---- the closest-hit kernel on its own: replaces Renderer::get_closest_hit
  * (renderer.rs:211-220) for a batch of rays (host arrays, n rays, xyz interleaved).

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPTGPU_LIB") or os.path.join(HERE, "lib", "librptgpu.so")  # RPTGPU_LIB: dev A/B builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 RPTGPU_OK = 0
 RPTGPU_E_INVALID_ARGUMENT = -1
@@ -101,7 +101,9 @@ class RptRenderParams(C.Structure):
 class RptStats(C.Structure):
     _fields_ = [("kernel_ms", f64 * RPT_K_COUNT), ("kernel_launches", C.c_uint64 * RPT_K_COUNT),
                 ("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shadow_rays_traced", C.c_uint64),
-                ("samples", C.c_uint64), ("total_ms", f64)]
+                ("samples", C.c_uint64), ("total_ms", f64),
+                ("reduce_calls", C.c_uint64), ("reduce_render_ms", f64), ("reduce_collective_ms", f64),
+                ("reduce_copy_ms", f64)]
 
 
 class RptKdTree(C.Structure):
@@ -128,6 +130,8 @@ SYMBOLS = [
     ("rptgpu_comm_init", C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
     ("rptgpu_comm_destroy", C.c_int, [_VP]),
     ("rptgpu_render_batch_reduce", C.c_int,
+     [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), C.c_int, C.POINTER(C.c_float)]),
+    ("rptgpu_render_batch_emulate_ranks", C.c_int,
      [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), C.c_int, C.POINTER(C.c_float)]),
     ("rptgpu_closest_hit", C.c_int,
      [_VP, C.c_uint64, _PD, _PD, C.c_uint32, _PD, _PD, C.POINTER(C.c_int32)]),

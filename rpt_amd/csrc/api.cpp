@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rpt_gpu.h"
@@ -72,11 +73,17 @@ struct Rccl {
   int (*CommDestroy)(RcclComm) = nullptr;
   int (*CommAbort)(RcclComm) = nullptr;
   int (*Reduce)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, int, RcclComm, hipStream_t) = nullptr;
+  // the gather (optional: without them rptgpu_render_batch_reduce falls back to the reduce)
+  int (*Send)(const void*, size_t, int, int /*peer*/, RcclComm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int /*peer*/, RcclComm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*CommGetAsyncError)(RcclComm, int*) = nullptr; // optional: polled while a batch's collective is in flight
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
   std::string why;
 };
-constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0; // ncclFloat32, ncclSum (rccl.h)
+constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0, RCCL_IN_PROGRESS = 7; // ncclFloat32, ncclSum, ncclInProgress (rccl.h)
 Rccl load_rccl() {
   Rccl r;
   // RPTGPU_FAIL_COMM=1: test hook — behave as if librccl.so could not be opened, so that the error paths of
@@ -107,6 +114,11 @@ Rccl load_rccl() {
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
   r.CommAbort = (decltype(r.CommAbort))dlsym(r.so, "ncclCommAbort"); // optional: the failure path of the reduce
   r.Reduce = (decltype(r.Reduce))dlsym(r.so, "ncclReduce");
+  r.Send = (decltype(r.Send))dlsym(r.so, "ncclSend");
+  r.Recv = (decltype(r.Recv))dlsym(r.so, "ncclRecv");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(r.so, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.so, "ncclGroupEnd");
+  r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(r.so, "ncclCommGetAsyncError");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Reduce;
   if (!r.ok) r.why = "librccl.so lacks an expected symbol";
@@ -198,10 +210,19 @@ struct rptgpu_scene {
   RcclComm comm = nullptr;
   int comm_rank = 0, comm_world = 1;
   DevBuf<float> frame32, frame32_sum;
+  // multi-GPU gather: this rank's packed pixels; on the root the peers' packed pixels and every rank's pixel list
+  DevBuf<float> packed32, gather32;
+  DevBuf<uint32_t> gather_pixels;          // [world] lists back to back, in rank order
+  std::vector<uint64_t> gather_off;        // [world + 1] offsets (pixels) into gather_pixels
+  uint32_t gather_key[5] = {0, 0, 0, 0, 0}; // width, height, world, root, 1
+  bool comm_failed = false;                // a batch's collective failed: sticky until comm_destroy + comm_init
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
   ~rptgpu_scene() {
     (void)hipSetDevice(device);
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev)
+      if (e) (void)hipEventDestroy(e);
     if (comm && rccl().ok) (void)rccl().CommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
     // every DevBuf member frees itself (its destructor runs after this body, on `device`)
@@ -301,23 +322,28 @@ void drain_events(rptgpu_scene* h) {
   h->ev_used = 0;
 }
 
+// the pixels of part pi of pc, in the order the path kernels walk them: 8x8-pixel blocks, row-major inside a block —
+// the 64 lanes of a wave start on one compact block, so their paths see the same part of the scene (coherent
+// traversal, similar lengths)
+std::vector<uint32_t> pixel_list(uint32_t width, uint32_t height, uint32_t tw, uint32_t th, uint32_t pi, uint32_t pc) {
+  std::vector<uint32_t> pix;
+  uint32_t tiles_x = (width + tw - 1) / tw;
+  pix.reserve((size_t)width * height / pc + 1);
+  for (uint32_t by = 0; by < height; by += 8)
+    for (uint32_t bx = 0; bx < width; bx += 8)
+      for (uint32_t y = by; y < std::min(by + 8, height); y++)
+        for (uint32_t x = bx; x < std::min(bx + 8, width); x++) {
+          uint32_t tile = (y / th) * tiles_x + (x / tw);
+          if (pc <= 1 || tile % pc == pi) pix.push_back(y * width + x);
+        }
+  return pix;
+}
 void ensure_partition(rptgpu_scene* h, const RptRenderParams& p) {
   uint32_t tw = p.tile_width ? p.tile_width : 32, th = p.tile_height ? p.tile_height : 8;
   uint32_t pc = p.part_count ? p.part_count : 1, pi = p.part_count ? p.part_index : 0;
   uint32_t key[6] = {p.width, p.height, tw, th, pi, pc};
   if (std::memcmp(key, h->part_key, sizeof key) == 0 && h->pixels.p) return;
-  std::vector<uint32_t> pix;
-  uint32_t tiles_x = (p.width + tw - 1) / tw;
-  pix.reserve((size_t)p.width * p.height / pc + 1);
-  // 8x8-pixel blocks, row-major inside a block: the 64 lanes of a wave start on one compact
-  // block, so their paths see the same part of the scene (coherent traversal, similar lengths)
-  for (uint32_t by = 0; by < p.height; by += 8)
-    for (uint32_t bx = 0; bx < p.width; bx += 8)
-      for (uint32_t y = by; y < std::min(by + 8, p.height); y++)
-        for (uint32_t x = bx; x < std::min(bx + 8, p.width); x++) {
-          uint32_t tile = (y / th) * tiles_x + (x / tw);
-          if (pc <= 1 || tile % pc == pi) pix.push_back(y * p.width + x);
-        }
+  std::vector<uint32_t> pix = pixel_list(p.width, p.height, tw, th, pi, pc);
   h->pixels.upload(pix, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->npix = (uint32_t)pix.size();
@@ -424,16 +450,21 @@ rptdev::Camera make_camera(const RptCamera& c) {
   return d;
 }
 
+// what is wrong with a batch's parameters (nullptr: nothing) — the same answer on every rank of a multi-GPU job
+const char* bad_params(const RptRenderParams* p) {
+  if (!p->width || !p->height || !p->iterations) return "width, height and iterations must be non-zero";
+  if (p->max_bounces > 254) return "max_bounces > 254";
+  if ((uint64_t)p->width * p->height >= (1ull << 31)) return "frame too large";
+  if (p->part_count && p->part_index >= p->part_count) return "part_index >= part_count";
+  if (p->precision_mode != RPT_PRECISION_F64_STRICT) return BAD_MODE;
+  return nullptr;
+}
+
+// packed (with d_out, f32 or f64): d_out receives only this part's pixels, [npix][3] in the order of the part's pixel list
 int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* p, void* d_out, bool out_f32,
-                double* host_out, hipStream_t user_stream) {
+                double* host_out, hipStream_t user_stream, bool packed = false) {
   if (!h || !camera || !p) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
-  if (!p->width || !p->height || !p->iterations)
-    return fail(h, RPTGPU_E_INVALID_ARGUMENT, "width, height and iterations must be non-zero");
-  if (p->max_bounces > 254) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "max_bounces > 254");
-  if ((uint64_t)p->width * p->height >= (1ull << 31)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "frame too large");
-  if (p->part_count && p->part_index >= p->part_count)
-    return fail(h, RPTGPU_E_INVALID_ARGUMENT, "part_index >= part_count");
-  if (p->precision_mode != RPT_PRECISION_F64_STRICT) return fail(h, RPTGPU_E_INVALID_ARGUMENT, BAD_MODE);
+  if (const char* why = bad_params(p)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, why);
   auto t0 = std::chrono::steady_clock::now();
   try {
     HIP_TRY(hipSetDevice(h->device));
@@ -453,7 +484,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       out = h->out_full.p;
     }
     if (user_stream) HIP_TRY(hipStreamSynchronize(user_stream));
-    HIP_TRY(hipMemsetAsync(out, 0, frame_elems * out_elem, st));
+    if (!packed) HIP_TRY(hipMemsetAsync(out, 0, frame_elems * out_elem, st));
     const bool wavefront = (p->flags & RPT_FLAG_WAVEFRONT)    ? true
                            : (p->flags & RPT_FLAG_PERSISTENT) ? false
                                                               : h->prefer_wavefront;
@@ -512,7 +543,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
       }
       HIP_TRY(hipGetLastError());
-      kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
+      kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32, packed);
       unsigned long long rc[16] = {0};
       HIP_TRY(hipMemcpyAsync(rc, h->pcounters.p, sizeof rc, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -624,7 +655,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         { Bracket b(h, RPT_K_RESOLVE, prof); kt->resolve(st, fr, ps, sc); b.done(); }
         HIP_TRY(hipGetLastError()); // a failed launch is reported here, not by the stream sync
       }
-      kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32);
+      kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32, packed);
       if (std::getenv("RPTGPU_PRINT_PHASES")) {
         HIP_TRY(hipStreamSynchronize(st));
         print_prof(kt, "wavefront");
@@ -704,6 +735,12 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
   {
     int nd = 0;
     bopt.device_build_min = 32768;
+    // several ranks on one node share the host's cores (host_scene.cpp usable_cpus): the device build pays earlier
+    for (const char* name : {"RPTGPU_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
+      if (const char* e = std::getenv(name)) {
+        if (std::atoi(e) > 1) bopt.device_build_min = 4096;
+        break;
+      }
     if (const char* e = std::getenv("RPTGPU_DEVICE_BUILD_MIN")) bopt.device_build_min = (size_t)std::max(0ll, std::atoll(e));
     if (bopt.device_build_min && hipGetDeviceCount(&nd) == hipSuccess && device >= 0 && device < nd) bopt.device = device;
     else (void)hipGetLastError();
@@ -987,6 +1024,7 @@ int rptgpu_comm_init(rptgpu_scene* h, int rank, int world, const uint8_t id[RPTG
   Rccl& r = rccl();
   if (!r.ok) return fail(h, RPTGPU_E_COMM, r.why);
   if (h->comm) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "the handle already has a communicator");
+  h->comm_failed = false;
   if (hipSetDevice(h->device) != hipSuccess) return fail(h, RPTGPU_E_HIP, "hipSetDevice");
   RcclUniqueId uid;
   std::memcpy(&uid, id, sizeof uid);
@@ -1005,37 +1043,115 @@ int rptgpu_comm_destroy(rptgpu_scene* h) {
     (void)rccl().CommDestroy(h->comm);
   }
   h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+  h->comm_failed = false;
   return RPTGPU_OK;
 }
+
+namespace {
+// the root's view of the gather: every rank's pixel list (the lists the ranks' own ensure_partition builds) on the device
+void ensure_gather_lists(rptgpu_scene* h, uint32_t width, uint32_t height, uint32_t world, uint32_t root) {
+  uint32_t key[5] = {width, height, world, root, 1u};
+  if (std::memcmp(key, h->gather_key, sizeof key) == 0 && h->gather_pixels.p) return;
+  std::vector<uint32_t> all;
+  all.reserve((size_t)width * height);
+  h->gather_off.assign(world + 1, 0);
+  for (uint32_t r = 0; r < world; r++) {
+    std::vector<uint32_t> pix = pixel_list(width, height, 32, 8, r, world);
+    all.insert(all.end(), pix.begin(), pix.end());
+    h->gather_off[r + 1] = all.size();
+  }
+  h->gather_pixels.upload(all, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream)); // `all` dies with this function
+  h->gather32.alloc(std::max<uint64_t>(1, all.size() * 3));
+  std::memcpy(h->gather_key, key, sizeof key);
+}
+double comm_timeout_s() {
+  if (const char* e = std::getenv("RPTGPU_COMM_TIMEOUT_S")) {
+    double v = std::atof(e);
+    if (v > 0.0) return v;
+  }
+  return 300.0;
+}
+} // namespace
 
 int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, int root,
                                float* out_rgb32) {
   if (!h || !camera || !params) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  if (h->comm_failed)
+    return fail(h, RPTGPU_E_COMM, "an earlier batch's collective failed on this handle: rptgpu_comm_destroy + rptgpu_comm_init before the next one");
   const int world = h->comm ? h->comm_world : 1, rank = h->comm ? h->comm_rank : 0;
+  // errors every rank makes alike: returned before anything is enqueued, the communicator stays as it is
   if (root < 0 || root >= world) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "root out of range");
-  if (rank == root && !out_rgb32) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null out_rgb32 on the root rank");
+  if (const char* why = bad_params(params)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, why);
   RptRenderParams p = *params;
   p.tile_width = 32; p.tile_height = 8; p.part_index = (uint32_t)rank; p.part_count = (uint32_t)world;
   const uint64_t n = (uint64_t)p.width * p.height * 3;
-  try {
-    HIP_TRY(hipSetDevice(h->device));
-    h->frame32.alloc(n);
-    if (world > 1 && rank == root) h->frame32_sum.alloc(n);
-  } catch (const HipError& e) {
-    return hip_fail(h, e);
-  }
-  // A rank that cannot take part in the collective must not leave the others waiting in it for ever: the
-  // communicator is aborted (ncclCommAbort makes the peers' pending operations fail) and dropped from the handle.
-  // After any failure here the communicator is gone on this rank; the caller tears the job down or re-initialises.
+  Rccl* rc_lib = world > 1 ? &rccl() : nullptr;
+  // From here on a failure is this rank's own (a null buffer on the root, out of memory, a HIP or RCCL error, a
+  // time-out): the peers are in, or on their way into, the batch's collective and must not wait for this rank for
+  // ever.  ncclCommAbort tears down this rank's side; the peers notice through ncclCommGetAsyncError or their own
+  // time-out (wait_stream below) and do the same.  The handle then refuses further batches until it gets a new
+  // communicator (comm_failed).
   auto abort_comm = [&] {
     if (world > 1 && h->comm) {
-      Rccl& r = rccl();
-      if (r.CommAbort) (void)r.CommAbort(h->comm);
+      if (rc_lib->CommAbort) (void)rc_lib->CommAbort(h->comm);
       h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+      h->comm_failed = true;
     }
   };
-  // the render leaves this rank's frame (zeros outside its tiles) in frame32; nothing is copied to the host yet
-  int rc = render_impl(h, camera, &p, h->frame32.p, true, nullptr, nullptr);
+  auto fail_comm = [&](int code, const std::string& why) {
+    abort_comm();
+    return fail(h, code, why);
+  };
+  if (rank == root && !out_rgb32) return fail_comm(RPTGPU_E_INVALID_ARGUMENT, "null out_rgb32 on the root rank");
+  // waits for the library's stream; with a communicator it polls the stream together with RCCL's asynchronous error
+  // state instead of blocking, so that a peer's failure ends this call too
+  auto wait_stream = [&]() -> int {
+    if (world <= 1) { HIP_TRY(hipStreamSynchronize(h->stream)); return RPTGPU_OK; }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(comm_timeout_s());
+    for (uint32_t spins = 0;; spins++) {
+      hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) return RPTGPU_OK;
+      if (q != hipErrorNotReady) throw HipError{q, "hipStreamQuery", __LINE__};
+      if (rc_lib->CommGetAsyncError) {
+        int aerr = 0;
+        int grc = rc_lib->CommGetAsyncError(h->comm, &aerr);
+        if (grc != 0 || (aerr != 0 && aerr != RCCL_IN_PROGRESS)) {
+          const int code = grc != 0 ? grc : aerr;
+          return fail_comm(RPTGPU_E_COMM, std::string("asynchronous RCCL error while the batch's collective was in flight: ") +
+                                              (rc_lib->GetErrorString ? rc_lib->GetErrorString(code) : "error"));
+        }
+      }
+      if (std::chrono::steady_clock::now() > deadline)
+        return fail_comm(RPTGPU_E_COMM, "the batch's collective did not finish within RPTGPU_COMM_TIMEOUT_S (a peer rank failed or hangs)");
+      if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  };
+  const char* mode_env = std::getenv("RPTGPU_COLLECTIVE");
+  bool gather = !(mode_env && std::strcmp(mode_env, "reduce") == 0);
+  if (world > 1 && gather && !(rc_lib->Send && rc_lib->Recv && rc_lib->GroupStart && rc_lib->GroupEnd)) gather = false;
+  try {
+    HIP_TRY(hipSetDevice(h->device));
+    for (auto& e : h->ev)
+      if (!e) HIP_TRY(hipEventCreate(&e));
+    if (rank == root) h->frame32_sum.alloc(n);
+    if (gather) {
+      ensure_partition(h, p);
+      h->packed32.alloc(std::max<uint64_t>(1, (uint64_t)h->npix * 3));
+      if (rank == root) ensure_gather_lists(h, p.width, p.height, (uint32_t)world, (uint32_t)root);
+    } else {
+      h->frame32.alloc(n);
+    }
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  } catch (const HipError& e) {
+    abort_comm();
+    return hip_fail(h, e);
+  } catch (const std::bad_alloc&) {
+    return fail_comm(RPTGPU_E_HIP, "out of host memory");
+  }
+  // this rank's tiles: gather — only its pixels, packed; reduce — the full frame with zeros elsewhere
+  int rc = gather ? render_impl(h, camera, &p, h->packed32.p, true, nullptr, nullptr, true)
+                  : render_impl(h, camera, &p, h->frame32.p, true, nullptr, nullptr);
   if (rc != RPTGPU_OK) {
     std::string detail = h->error; // keep the render's own message
     abort_comm();
@@ -1043,21 +1159,101 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
     return rc;
   }
   try {
-    float* result = h->frame32.p;
-    if (world > 1) {
-      Rccl& r = rccl();
-      int nrc = r.Reduce(h->frame32.p, rank == root ? h->frame32_sum.p : nullptr, (size_t)n, RCCL_FLOAT32, RCCL_SUM, root, h->comm, h->stream);
-      if (nrc != 0) {
-        (void)hipStreamSynchronize(h->stream);
-        abort_comm();
-        return fail(h, RPTGPU_E_COMM, std::string("ncclReduce: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "error"));
+    const KernelTable* kt = table_for(p.precision_mode, h->ext_shapes);
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    float* result = nullptr;
+    if (gather) {
+      if (world > 1) {
+        int nrc = rc_lib->GroupStart();
+        if (nrc == 0) {
+          if (rank == root) {
+            for (int r = 0; r < world && nrc == 0; r++) {
+              if (r == root) continue;
+              const uint64_t cnt = (h->gather_off[r + 1] - h->gather_off[r]) * 3;
+              if (cnt) nrc = rc_lib->Recv(h->gather32.p + h->gather_off[r] * 3, (size_t)cnt, RCCL_FLOAT32, r, h->comm, h->stream);
+            }
+          } else if (h->npix) {
+            nrc = rc_lib->Send(h->packed32.p, (size_t)h->npix * 3, RCCL_FLOAT32, root, h->comm, h->stream);
+          }
+          const int erc = rc_lib->GroupEnd();
+          if (nrc == 0) nrc = erc;
+        }
+        if (nrc != 0) {
+          (void)hipStreamSynchronize(h->stream);
+          return fail_comm(RPTGPU_E_COMM, std::string("ncclSend / ncclRecv: ") + (rc_lib->GetErrorString ? rc_lib->GetErrorString(nrc) : "error"));
+        }
       }
-      result = h->frame32_sum.p;
+      HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+      if (rank == root) { // every rank's pixels into their places; between them the lists cover the frame exactly once
+        for (int r = 0; r < world; r++) {
+          const uint64_t off = h->gather_off[r], cnt = h->gather_off[r + 1] - off;
+          kt->scatter_f32(h->stream, r == root ? h->packed32.p : h->gather32.p + off * 3, h->gather_pixels.p + off, (uint32_t)cnt, h->frame32_sum.p);
+        }
+        HIP_TRY(hipGetLastError());
+        result = h->frame32_sum.p;
+      }
+    } else {
+      result = h->frame32.p;
+      if (world > 1) {
+        int nrc = rc_lib->Reduce(h->frame32.p, rank == root ? h->frame32_sum.p : nullptr, (size_t)n, RCCL_FLOAT32, RCCL_SUM, root, h->comm, h->stream);
+        if (nrc != 0) {
+          (void)hipStreamSynchronize(h->stream);
+          return fail_comm(RPTGPU_E_COMM, std::string("ncclReduce: ") + (rc_lib->GetErrorString ? rc_lib->GetErrorString(nrc) : "error"));
+        }
+        result = h->frame32_sum.p;
+      }
+      HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     }
     if (rank == root) HIP_TRY(hipMemcpyAsync(out_rgb32, result, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    if (int wrc = wait_stream(); wrc != RPTGPU_OK) return wrc;
+    float ms[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
+    h->stats.reduce_calls += 1;
+    h->stats.reduce_render_ms += ms[0];
+    h->stats.reduce_collective_ms += ms[1];
+    h->stats.reduce_copy_ms += ms[2];
   } catch (const HipError& e) {
     abort_comm();
+    return hip_fail(h, e);
+  } catch (const std::bad_alloc&) {
+    return fail_comm(RPTGPU_E_HIP, "out of host memory");
+  }
+  return RPTGPU_OK;
+}
+
+int rptgpu_render_batch_emulate_ranks(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, int world,
+                                      float* out_rgb32) {
+  if (!h || !camera || !params || !out_rgb32) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  if (world < 1 || world > 4096) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "world out of range");
+  if (const char* why = bad_params(params)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, why);
+  const uint64_t n = (uint64_t)params->width * params->height * 3;
+  try {
+    HIP_TRY(hipSetDevice(h->device));
+    h->frame32_sum.alloc(n);
+    ensure_gather_lists(h, params->width, params->height, (uint32_t)world, 0u);
+    HIP_TRY(hipMemsetAsync(h->frame32_sum.p, 0xff, n * sizeof(float), h->stream)); // NaNs: a pixel nobody places shows
+  } catch (const HipError& e) {
+    return hip_fail(h, e);
+  }
+  // what each rank would send, rendered here one after the other straight into the root's receive buffer
+  for (int r = 0; r < world; r++) {
+    RptRenderParams p = *params;
+    p.tile_width = 32; p.tile_height = 8; p.part_index = (uint32_t)r; p.part_count = (uint32_t)world;
+    if (h->gather_off[r + 1] == h->gather_off[r]) continue; // a rank without a tile (more ranks than tiles)
+    int rc = render_impl(h, camera, &p, h->gather32.p + h->gather_off[r] * 3, true, nullptr, nullptr, true);
+    if (rc != RPTGPU_OK) return rc;
+  }
+  try {
+    const KernelTable* kt = table_for(params->precision_mode, h->ext_shapes);
+    for (int r = 0; r < world; r++) {
+      const uint64_t off = h->gather_off[r], cnt = h->gather_off[r + 1] - off;
+      kt->scatter_f32(h->stream, h->gather32.p + off * 3, h->gather_pixels.p + off, (uint32_t)cnt, h->frame32_sum.p);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rgb32, h->frame32_sum.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } catch (const HipError& e) {
     return hip_fail(h, e);
   }
   return RPTGPU_OK;

@@ -39,6 +39,14 @@ int usable_cpus() {
       n = std::min(n, std::max(1, (int)(std::atof(quota) / period)));
     std::fclose(f);
   }
+  // one process per GPU: the ranks of a node build their scenes at the same time on the same cores.  LOCAL_WORLD_SIZE is
+  // what torch.distributed.run exports; RPTGPU_LOCAL_RANKS says the same for other launchers.
+  for (const char* name : {"RPTGPU_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
+    if (const char* e = std::getenv(name)) {
+      const int ranks = std::atoi(e);
+      if (ranks > 1) n = std::max(1, n / ranks);
+      break;
+    }
   return n;
 }
 

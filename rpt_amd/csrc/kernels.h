@@ -85,7 +85,10 @@ struct KernelTable {
   void (*shadow_rays)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* sq,
                       const uint32_t* sq_count, uint32_t n, int light, double* srt);
   void (*resolve)(hipStream_t, const rptdev::Frame&, const rptdev::PathState&, uint32_t n_samples);
-  void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32);
+  // means into the full frame, or `packed` into a compact [npix][3] array in the order of Frame::pixels
+  void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32, bool packed);
+  // multi-GPU gather, root side: one rank's packed pixels into their places in the full f32 frame
+  void (*scatter_f32)(hipStream_t, const float* src, const uint32_t* pixels, uint32_t n, float* dst);
   void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
   // persistent per-pixel kernel: resident 64-thread blocks per CU, and the launch
   int (*paths_max_blocks_per_cu)(bool flat, uint32_t lds_bytes);

@@ -83,13 +83,23 @@ class GpuScene:
         _abi.check(self.lib.rptgpu_comm_destroy(self.handle), self.handle)
 
     def render_batch_reduce(self, camera, params, root=0, out=None):
-        """Renderer::sample on every rank: this rank's tiles, ncclReduce(sum) of the f32 frames to `root`,
-        result in host memory on root.  `out`: float32 array of width*height*3 (allocated if None on root)."""
+        """Renderer::sample on every rank: this rank's tiles, the owned pixels gathered on `root` over RCCL
+        (RPTGPU_COLLECTIVE=reduce: ncclReduce(sum) of zero-filled frames), result in host memory on root.  `out`: float32 array of width*height*3 (allocated if None on root)."""
         cam = camera.lower() if hasattr(camera, "lower") else camera
         if out is None:
             out = np.empty(params.height * params.width * 3, dtype=np.float32)
         code = self.lib.rptgpu_render_batch_reduce(self.handle, C.byref(cam), C.byref(params), int(root),
                                                    out.ctypes.data_as(C.POINTER(C.c_float)))
+        _abi.check(code, self.handle)
+        return out
+
+    def render_batch_emulate_ranks(self, camera, params, world, out=None):
+        """Diagnostics: the frame as `world` ranks' gather would assemble it, on this one GPU (include/rpt_gpu.h)."""
+        cam = camera.lower() if hasattr(camera, "lower") else camera
+        if out is None:
+            out = np.empty(params.height * params.width * 3, dtype=np.float32)
+        code = self.lib.rptgpu_render_batch_emulate_ranks(self.handle, C.byref(cam), C.byref(params), int(world),
+                                                          out.ctypes.data_as(C.POINTER(C.c_float)))
         _abi.check(code, self.handle)
         return out
 

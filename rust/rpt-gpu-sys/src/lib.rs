@@ -21,7 +21,7 @@ use std::sync::Arc;
 pub mod ffi {
     use std::os::raw::{c_char, c_int, c_void};
 
-    pub const RPTGPU_ABI_VERSION: c_int = 4;
+    pub const RPTGPU_ABI_VERSION: c_int = 5;
     pub const RPTGPU_OK: c_int = 0;
     pub const RPTGPU_E_INVALID_ARGUMENT: c_int = -1;
     pub const RPTGPU_E_UNSUPPORTED_SHAPE: c_int = -2;
@@ -187,6 +187,10 @@ pub mod ffi {
         pub shadow_rays_traced: u64,
         pub samples: u64,
         pub total_ms: f64,
+        pub reduce_calls: u64,
+        pub reduce_render_ms: f64,
+        pub reduce_collective_ms: f64,
+        pub reduce_copy_ms: f64,
     }
 
     #[repr(C)]
@@ -226,6 +230,7 @@ pub mod ffi {
         pub fn rptgpu_comm_init(h: *mut rptgpu_scene, rank: c_int, world: c_int, id: *const u8) -> c_int;
         pub fn rptgpu_comm_destroy(h: *mut rptgpu_scene) -> c_int;
         pub fn rptgpu_render_batch_reduce(h: *mut rptgpu_scene, camera: *const RptCamera, params: *const RptRenderParams, root: c_int, out_rgb32: *mut f32) -> c_int;
+        pub fn rptgpu_render_batch_emulate_ranks(h: *mut rptgpu_scene, camera: *const RptCamera, params: *const RptRenderParams, world: c_int, out_rgb32: *mut f32) -> c_int;
         pub fn rptgpu_closest_hit(h: *mut rptgpu_scene, n: u64, origins: *const f64, dirs: *const f64, precision_mode: u32, out_t: *mut f64, out_normal: *mut f64, out_object: *mut i32) -> c_int;
         pub fn rptgpu_kdtree_build(boxes: *const f64, n: u64, out: *mut RptKdTree) -> c_int;
         pub fn rptgpu_kdtree_build_device(boxes: *const f64, n: u64, device: c_int, out: *mut RptKdTree) -> c_int;
@@ -480,8 +485,8 @@ impl GpuScene {
         check(unsafe { ffi::rptgpu_render_batch(self.h, camera, params, out_rgb.as_mut_ptr()) }, self.h)
     }
 
-    /// Multi-GPU form (one process per GPU): renders this rank's tiles, `ncclReduce`s the f32 frames to `root`
-    /// inside the library and fills `out_rgb32` on the root rank.
+    /// Multi-GPU form (one process per GPU): renders this rank's tiles, gathers the owned pixels on `root` inside the
+    /// library (RCCL send / receive; `RPTGPU_COLLECTIVE=reduce` for an `ncclReduce`) and fills `out_rgb32` on the root rank.
     pub fn render_batch_reduce(&mut self, camera: &RptCamera, params: &RptRenderParams, root: i32, out_rgb32: &mut [f32]) -> Result<(), GpuError> {
         assert_eq!(out_rgb32.len(), params.width as usize * params.height as usize * 3);
         // SAFETY: as above
@@ -518,7 +523,7 @@ impl GpuScene {
     }
 
     pub fn stats(&self) -> Result<RptStats, GpuError> {
-        let mut s = RptStats { kernel_ms: [0.0; 8], kernel_launches: [0; 8], extend_rays: 0, shadow_rays: 0, shadow_rays_traced: 0, samples: 0, total_ms: 0.0 };
+        let mut s = RptStats { kernel_ms: [0.0; 8], kernel_launches: [0; 8], extend_rays: 0, shadow_rays: 0, shadow_rays_traced: 0, samples: 0, total_ms: 0.0, reduce_calls: 0, reduce_render_ms: 0.0, reduce_collective_ms: 0.0, reduce_copy_ms: 0.0 };
         // SAFETY: out-pointer to a local
         check(unsafe { ffi::rptgpu_get_stats(self.h, &mut s) }, self.h)?;
         Ok(s)
@@ -557,7 +562,7 @@ mod layout_tests {
         assert_eq!(size_of::<RptScene>(), 80);
         assert_eq!(size_of::<RptCamera>(), 96);
         assert_eq!(size_of::<RptRenderParams>(), 64);
-        assert_eq!(size_of::<RptStats>(), 168);
+        assert_eq!(size_of::<RptStats>(), 200);
         assert_eq!(size_of::<RptKdTree>(), 64);
     }
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == {s[0] for s in _abi.SYMBOLS}
-    assert lib.rptgpu_abi_version() == _abi.ABI_VERSION == 4
+    assert lib.rptgpu_abi_version() == _abi.ABI_VERSION == 5
 
 
 def test_struct_sizes_match_header(tmp_path):

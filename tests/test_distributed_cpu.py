@@ -42,9 +42,17 @@ def _worker(rank, world, port, out_path):
         frame = torch.zeros(80 * 45 * 3, dtype=dtype)
         D.render_frame_sharded(render_part, params, rank, world, frame, dst=0)
         dist.barrier()
+        # the same frame through the gather (what librptgpu's collective does: only owned pixels travel)
+        gframe = torch.full((80 * 45 * 3,), float("nan"), dtype=dtype)
+        part = torch.zeros(80 * 45 * 3, dtype=dtype)
+        render_part(D.shard_params(params, rank, world), part)
+        own = torch.from_numpy(D.owned_pixels(80, 45, rank, world))
+        gframe.view(-1, 3)[own] = part.view(-1, 3)[own]
+        D.gather_frame(gframe, 80, 45, rank, world, dst=0)
+        dist.barrier()
         if rank == 0:
             full = torch.from_numpy(osc.render(cam, params, threads=1).reshape(-1)).to(dtype)
-            ok = bool((frame == full).all())
+            ok = bool((frame == full).all()) and bool((gframe == full).all())
             own = D.shard_params(params, 0, world)
             own_frame = osc.render(cam, own, threads=1)
             covered = float((own_frame != 0).any(axis=1).mean())

@@ -695,6 +695,31 @@ def test_library_collective_single_rank_communicator(built):
     g2.close()
 
 
+def test_gather_and_reduce_give_the_frame_of_a_plain_render(built, monkeypatch):
+    """The batch's collective is a gather of the pixels each rank owns (default) or an ncclReduce of zero-filled frames
+    (RPTGPU_COLLECTIVE=reduce): with a 1-rank communicator both must return the plain render; RptStats splits the
+    batch's time.  The gather of N ranks minus the wire (every rank's packed pixels placed by the root's lists) is
+    replayed on this one GPU for N = 1, 2, 3, 8 and more ranks than tiles, on a frame whose edge tiles are ragged."""
+    scene, cam, p, g = built("cornell")
+    pr = make_params(75, 41, p.max_bounces, 3, p.exposure_value, p.seed)
+    ref = g.render_batch(cam, pr).astype(np.float32).ravel()
+    for mode in ("gather", "reduce"):
+        monkeypatch.setenv("RPTGPU_COLLECTIVE", mode)
+        g2 = GpuScene(scene, 0)
+        g2.comm_init(0, 1, GpuScene.comm_unique_id())
+        g2.reset_stats()
+        assert (g2.render_batch_reduce(cam, pr, root=0) == ref).all(), mode
+        assert (g2.render_batch_reduce(cam, pr, root=0) == ref).all(), mode
+        st = g2.stats()
+        assert st.reduce_calls == 2 and st.reduce_render_ms > 0.0 and st.reduce_collective_ms >= 0.0 and st.reduce_copy_ms > 0.0
+        g2.close()
+    monkeypatch.delenv("RPTGPU_COLLECTIVE")
+    for world in (1, 2, 3, 8, 64):
+        assert (g.render_batch_emulate_ranks(cam, pr, world) == ref).all(), world
+    with pytest.raises(rpt_amd.RptGpuError):
+        g.render_batch_emulate_ranks(cam, pr, 0)
+
+
 def test_scene_destroy_releases_device_memory():
     # every device allocation behind a handle (scene, workspace, per-sample radiance buffer, sort buffers) is
     # returned by rptgpu_scene_destroy: create / render / destroy in a loop keeps free HBM where it was
