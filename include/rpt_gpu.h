@@ -39,7 +39,7 @@ enum {
   RPTGPU_E_NO_DEVICE = -3,         /* no HIP device / HIP runtime failure at init              */
   RPTGPU_E_HIP = -4,               /* a HIP call failed; see rptgpu_last_error_detail          */
   RPTGPU_E_OUT_OF_MEMORY = -5,
-  RPTGPU_E_TREE_TOO_DEEP = -6,     /* kd-tree deeper than the device traversal stack           */
+  RPTGPU_E_TREE_TOO_DEEP = -6,     /* (not returned for any input since ABI v5; internal check)  */
   RPTGPU_E_UNIMPLEMENTED_SAMPLE = -7, /* Light::Object over a Plane: plane.rs:34-36 panics     */
   RPTGPU_E_COMM = -8               /* RCCL is not available or a collective failed             */
 };
@@ -81,12 +81,11 @@ enum {
                            MONOMIAL, or another GROUP — each optionally Transformed (a PLANE is not
                            Bounded, kdtree.rs:9-12, and is refused).  MESH children that share one
                            triangle array (Arc<Mesh>) share one tree on the device.  NESTING: GROUPs may
-                           contain GROUPs down to four group levels (scene -> group -> group -> group ->
-                           group -> mesh / primitive); a fifth returns RPTGPU_E_UNSUPPORTED_SHAPE.  The
-                           reference nests without bound (kdtree.rs:14-24 forwards Bounded through Box);
-                           on the device every level is one more instantiation of the group traversal
-                           (out of line: code size and build time, not registers), so the depth is fixed
-                           — at twice what the reference's examples use */
+                           contain GROUPs to any depth, as in the reference (kdtree.rs:14-24 forwards
+                           Bounded through Box).  A group with tree children is walked by the per-tree
+                           kernels of the wavefront pipeline (two regular levels in one loop, anything else
+                           by the generic walker); RPT_FLAG_PERSISTENT is ignored for such a scene.  Only a
+                           Light::Object's shape keeps a limit: eight group levels (Shape::sample) */
   RPT_SHAPE_MONOMIAL = 5 /* src/shape/monomial_surface.rs:12-18  y = height*(x^2+z^2)^(exp/2),
                             x^2+z^2 <= 1; like the reference, intersection and normals are
                             only valid for exp = 4 (monomial_surface.rs:10): any other exp is

@@ -172,10 +172,15 @@ struct rptgpu_scene {
   // deep-tree scenes: per top-level object flags and the buffers of the object-by-object query
   std::vector<uint8_t> obj_deep, obj_tris, light_casts;
   // every per-tree object of the scene is one only by the kd-trees-of-kd-trees rule (shallow group, mesh children): for
-  // passes below nest_min_paths the object loop of rpt_extend is faster than five launches per object and query
   // (fractal_teapots at 8 bounces, 3.8 M paths per pass: 60.7 against 56.9 Msamples/s; 7.7 M: 70.6 against 86.7)
-  bool deep_only_nests = false;
-  uint32_t nest_min_paths = 6u << 20; // RPTGPU_NEST_MIN_PATHS
+  bool tree_kids = false;   // some object is a group with tree children, or a tree too deep for the in-kernel
+                            // traversals: only the per-tree pipeline walks those
+  uint32_t max_tree_depth = 0;
+  uint32_t gen_levels = 0, gen_frames = 0; // rpt_tree_generic's column heights for this scene (host_scene.cpp)
+  bool gen_all = false;     // some object sends EVERY ray through rpt_tree_generic (irregular tree, generic_only)
+  DevBuf<double> gen_defer, gen_frame;
+  DevBuf<uint32_t> gen_overflow;
+  uint32_t gen_threads = 0;
   std::vector<rptdev::Light> host_lights; // (what launch decisions need of the lights)
   std::vector<uint32_t> cnt_host;  // the per-depth counters read back from the device
   bool has_deep = false;
@@ -350,6 +355,26 @@ void ensure_partition(rptgpu_scene* h, const RptRenderParams& p) {
   std::memcpy(h->part_key, key, sizeof key);
 }
 
+// rpt_tree_generic's columns: a small grid for the few rays the fast kernels hand on, a large one when whole objects
+// (or, under RPT_FLAG_GENERAL_TRAVERSAL, everything) go through it.  Heights: what the scene's deepest nest needs.
+void ensure_generic(rptgpu_scene* h, bool all) {
+  const uint32_t blocks_few = 64, blocks_all = (uint32_t)std::max(64, std::min(1024, h->num_cus * 4));
+  const uint32_t want = (all ? blocks_all : blocks_few) * 256u;
+  if (h->gen_threads < want) {
+    const uint64_t levels = std::max(1u, h->gen_levels), frames = std::max(1u, h->gen_frames);
+    h->gen_defer.release(); h->gen_frame.release();
+    h->gen_defer.alloc(levels * 8u * want);
+    h->gen_frame.alloc(frames * 12u * want);
+    h->gen_overflow.alloc(1);
+    HIP_TRY(hipMemsetAsync(h->gen_overflow.p, 0, sizeof(uint32_t), h->stream));
+    h->gen_threads = want;
+  }
+  h->spill.gen = GenericStack{h->gen_defer.p, h->gen_frame.p, h->gen_threads, std::max(1u, h->gen_levels), std::max(1u, h->gen_frames)};
+  h->spill.gen_overflow = h->gen_overflow.p;
+  h->spill.gen_blocks_few = blocks_few;
+  h->spill.gen_blocks_all = h->gen_threads / 256u >= blocks_all ? blocks_all : blocks_few;
+}
+
 void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   if (cap <= h->ws_cap && max_bounces <= h->ws_bounces && h->ray.p) return;
   cap = std::max(cap, h->ws_cap);
@@ -374,9 +399,9 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   if (h->has_deep) {
     h->tq.alloc(3 * cap); // a tree's ray queue | its rays with a zero direction component | those handed to the general form
     h->tq_ctr.alloc(5);
-    { // the traversal grid's stack spill area: one column per thread, KD_MAX_STACK - RPT_TT_LEVELS levels
+    { // the traversal grid's stack spill area: one column per thread, as high as the scene's deepest tree (at least KD_MAX_STACK) less the LDS levels
       const uint64_t threads = (uint64_t)std::max(1, h->num_cus * 4) / 4 * RPT_TT_WAVES * 256;
-      const uint64_t levels = (uint64_t)(rptdev::KD_MAX_STACK - RPT_TT_LEVELS);
+      const uint64_t levels = (uint64_t)(std::max<uint32_t>((uint32_t)rptdev::KD_MAX_STACK, h->max_tree_depth + 1u) - RPT_TT_LEVELS);
       h->spill_node.alloc(levels * threads); h->spill_ts.alloc(levels * threads); h->spill_bmax.alloc(levels * threads);
       uint32_t zeros_common = 0; // every shadow ray towards an axis-parallel directional light has a zero component
       for (const rptdev::Light& l : h->host_lights)
@@ -384,6 +409,7 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
       h->tree_rays.alloc(8 * cap); // one 64-byte row per position of a query: the rays that enter a tree (StackSpill::rays)
       h->spill = StackSpill{h->spill_node.p, h->spill_ts.p, h->spill_bmax.p, (uint32_t)threads, zeros_common, h->tree_rays.p};
     }
+    ensure_generic(h, h->gen_all);
     if (h->sort_rays) {
       h->sort_kin.alloc(cap); h->sort_kout.alloc(cap); h->sort_vin.alloc(cap);
       size_t bytes = rpt_strict::TABLE.sort_temp_bytes((uint32_t)cap);
@@ -485,9 +511,11 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     }
     if (user_stream) HIP_TRY(hipStreamSynchronize(user_stream));
     if (!packed) HIP_TRY(hipMemsetAsync(out, 0, frame_elems * out_elem, st));
-    const bool wavefront = (p->flags & RPT_FLAG_WAVEFRONT)    ? true
-                           : (p->flags & RPT_FLAG_PERSISTENT) ? false
-                                                              : h->prefer_wavefront;
+    // (a group with tree children is only walked by the per-tree kernels of the wavefront pipeline: RPT_FLAG_PERSISTENT
+    // is a request such a scene cannot honour, not an error)
+    const bool wavefront = (p->flags & RPT_FLAG_WAVEFRONT) || h->tree_kids ? true
+                           : (p->flags & RPT_FLAG_PERSISTENT)             ? false
+                                                                          : h->prefer_wavefront;
     h->dscene.force_general = (p->flags & RPT_FLAG_GENERAL_TRAVERSAL) ? 1 : 0;
     if (npix && !wavefront) {
       // ---- default pipeline: one persistent kernel, the whole path in registers
@@ -584,6 +612,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           s_chunk = std::max(1u, s_chunk / 2);
         }
       }
+      if (h->has_deep && (h->gen_all || h->dscene.force_general)) ensure_generic(h, true);
       h->accum.alloc((uint64_t)npix * 3);
       HIP_TRY(hipMemsetAsync(h->accum.p, 0, (uint64_t)npix * 3 * sizeof(double), st));
 
@@ -608,9 +637,10 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         const uint32_t* queue = nullptr; // identity at depth 0
         uint32_t* next = h->queue_a.p;
         for (uint32_t depth = 0; depth <= p->max_bounces && n_active; depth++) {
-          // (a pass too small to pay for a nest's per-tree launches — see nest_min_paths — walks the scene in-kernel)
-          const bool by_object = h->has_deep && !(p->flags & RPT_FLAG_GENERAL_TRAVERSAL) &&
-                                 !(h->deep_only_nests && n_paths < h->nest_min_paths);
+          // per-tree queries for scenes with deep trees; under RPT_FLAG_GENERAL_TRAVERSAL the whole scene is walked
+          // in-kernel in the general form — unless it has a group with tree children, which only the per-tree pipeline
+          // walks (there the flag sends every ray of every such object through rpt_tree_generic)
+          const bool by_object = h->has_deep && (!(p->flags & RPT_FLAG_GENERAL_TRAVERSAL) || h->tree_kids);
           const uint32_t trace_blocks = (uint32_t)std::max(1, h->num_cus * 4);
           { Bracket b(h, RPT_K_EXTEND, prof);
             if (by_object)
@@ -663,8 +693,15 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     }
     HIP_TRY(hipGetLastError());
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, frame_elems * out_elem, hipMemcpyDeviceToHost, st));
+    uint32_t gen_overflow = 0; // rpt_tree_generic outgrew its columns: they are sized from the scene, so this is a bug, not an input
+    if (wavefront && h->has_deep && h->gen_overflow.p)
+      HIP_TRY(hipMemcpyAsync(&gen_overflow, h->gen_overflow.p, sizeof gen_overflow, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (prof) drain_events(h);
+    if (gen_overflow) {
+      (void)hipMemsetAsync(h->gen_overflow.p, 0, sizeof(uint32_t), st);
+      return fail(h, RPTGPU_E_TREE_TOO_DEEP, "rpt_tree_generic: the traversal outgrew the stack sized for this scene (internal error)");
+    }
   } catch (const HipError& e) {
     h->pending.clear();
     h->ev_used = 0;
@@ -769,8 +806,12 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     h->num_cus = prop.multiProcessorCount;
     lap("device, stream, properties");
     h->prefer_wavefront = fs.max_tree_depth >= 3;
-    bool any_deep_by_depth = false;
-    if (const char* e = std::getenv("RPTGPU_NEST_MIN_PATHS")) h->nest_min_paths = (uint32_t)std::max(0, std::atoi(e));
+    // RPTGPU_FAST_MAX_DEPTH (tests): treat trees deeper than this as too deep for the in-kernel traversals.  The build rule
+    // itself keeps real trees far below 32: both children of a median split hold (n + straddlers) / 2 primitives, so a path
+    // d levels long needs 16 / 0.85^d primitives with an unsplittable sibling at every level, or 16 * 2^d balanced ones.
+    uint32_t fast_max_depth = (uint32_t)rptdev::KD_MAX_STACK;
+    if (const char* e = std::getenv("RPTGPU_FAST_MAX_DEPTH")) fast_max_depth = (uint32_t)std::max(0, std::min(std::atoi(e), (int)rptdev::KD_MAX_STACK));
+    h->max_tree_depth = fs.max_tree_depth;
     uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
     if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RPTGPU_RAYS_IN_KERNEL")) h->rays_in_kernel = std::atoi(e) != 0 ? 1 : 0;
@@ -780,16 +821,15 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       const rptdev::Inst& in = fs.insts[i];
       bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
       bool deep = tree && fs.tree_depth[in.tree] >= deep_depth;
-      // a kd-tree of kd-trees (fractal_teapots.rs) goes through the per-tree kernels whatever its own depth: the work
-      // is in the children's trees, and rpt_tree_trace (lean, four waves per SIMD, rays that miss the bounds never
-      // enter, lanes refilled) walks the nest 15 % faster than the object loop of rpt_extend: 84 -> 97 Msamples/s at
-      // 8 bounces.  Groups of spheres are the opposite case (C4 per-tree: 416 -> 278).  RPTGPU_NEST_PER_TREE=0: off
-      const bool deep_by_depth = deep;
-      if (tree && !deep && in.kind == RPT_SHAPE_GROUP && fs.trees[in.tree].mesh_kids) { // (also a single-leaf group: fractal_teapots' first two levels, 1 and 6 teapots)
-        const char* e = std::getenv("RPTGPU_NEST_PER_TREE");
-        deep = !e || std::atoi(e) != 0;
-      }
-      if (deep_by_depth) any_deep_by_depth = true;
+      // A group with TREE children (meshes: fractal_teapots.rs; groups: kdtree.rs:14-24 nests without limit) goes through
+      // the per-tree kernels whatever its own depth — they are the only ones that walk a tree inside a tree: rpt_nest_trace
+      // (two regular levels, one loop) or rpt_tree_generic (anything).  So does a tree deeper than the fast stacks.
+      const bool kids = in.kind == RPT_SHAPE_GROUP && fs.tree_kids[in.tree] != 0;
+      // deeper than the private stacks of the in-kernel traversals (KD_MAX_STACK): the per-tree kernels, whose stack
+      // beyond the LDS levels is a global column as high as the scene's deepest tree (ensure_workspace)
+      const bool too_deep = tree && fs.tree_depth[in.tree] > fast_max_depth;
+      deep = deep || kids || too_deep;
+      h->tree_kids = h->tree_kids || kids || too_deep; // (= some object is for the per-tree pipeline only)
       // rays entering a large tree are sorted by entry cell and octant first: neighbours in a wave then walk the same
       // nodes.  Measured with the VALU-bound traversal kernel of round 2: 100k-triangle mesh (66 MB of nodes + leaf
       // records) 144 -> 172 Msamples/s, 16k-triangle glass (17 MB) 469 -> 528, a 25k-triangle mesh under few bounces
@@ -804,20 +844,17 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
                          (next_ref - tr.ref_base) * (sizeof(uint32_t) + (in.kind == RPT_SHAPE_MESH ? sizeof(rptdev::TriX) : 0));
         sort = h->sort_mode == 1 || (h->sort_mode < 0 && bytes >= h->sort_min_bytes);
       }
-      h->sort_rays = h->sort_rays || sort;
-      // obj_deep: 0 in-kernel; 1 per-tree; 2 per-tree with the ray sort; +4: the tree is irregular or the general form is
-      // forced at handle level — every ray of it goes through rpt_tree_general
-      h->obj_deep.push_back(deep ? (uint8_t)((sort ? 2 : 1) | ((!fs.trees[in.tree].regular) ? 4 : 0)) : 0);
-      // which traversal kernel of the per-tree pipeline: 1 rpt_tree_trace<TRIS>, 0 rpt_tree_trace over a group, 2 a group
-      // with mesh children whose two levels fit one traversal stack: rpt_nest_trace (RPTGPU_NEST_TRACE=0: the nested form)
+      // which traversal kernel of the per-tree pipeline: 1 rpt_tree_trace<TRIS>, 0 rpt_tree_trace over a group of simple
+      // shapes, 2 a group with mesh children whose two regular levels fit one traversal stack: rpt_nest_trace
+      // (RPTGPU_NEST_TRACE=0: rpt_tree_generic instead), 3 rpt_tree_generic alone (Tree::generic_only)
       uint8_t trace_kind = in.kind == RPT_SHAPE_MESH ? 1 : 0;
-      if (deep && in.kind == RPT_SHAPE_GROUP && fs.trees[in.tree].mesh_kids && fs.trees[in.tree].regular) {
+      bool generic_only = false;
+      if (kids) {
         const rptdev::Tree& tr = fs.trees[in.tree];
         uint32_t inner_depth = 0;
-        bool ok = true; // rpt_nest_trace makes no calls: no group children, no irregular child trees
+        bool ok = tr.regular && !(fs.tree_kids[in.tree] & 2u); // rpt_nest_trace: no group children, no irregular trees
         for (uint32_t k = 0; k < tr.num_prims; k++) {
           const rptdev::Inst& kid = fs.insts[tr.prim_base + k];
-          if (kid.kind == RPT_SHAPE_GROUP) ok = false;
           if (kid.kind == RPT_SHAPE_MESH) {
             inner_depth = std::max(inner_depth, fs.tree_depth[kid.tree]);
             ok = ok && fs.trees[kid.tree].regular;
@@ -825,11 +862,24 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         }
         const char* e = std::getenv("RPTGPU_NEST_TRACE");
         if (ok && (!e || std::atoi(e) != 0) && fs.tree_depth[in.tree] + inner_depth + 2 <= (uint32_t)rptdev::KD_MAX_STACK) trace_kind = 2;
+        else generic_only = true;
       }
+      if (generic_only) {
+        trace_kind = 3;
+        fs.trees[in.tree].generic_only = 1u;
+        sort = false;
+      }
+      h->sort_rays = h->sort_rays || sort;
+      // obj_deep: 0 in-kernel; 1 per-tree; 2 per-tree with the ray sort; +4: every ray of it goes through rpt_tree_generic
+      // (an irregular tree, an object only that kernel is built for)
+      const bool all_generic = deep && (generic_only || !fs.trees[in.tree].regular);
+      h->gen_all = h->gen_all || all_generic;
+      h->obj_deep.push_back(deep ? (uint8_t)((sort ? 2 : 1) | (all_generic ? 4 : 0)) : 0);
       h->obj_tris.push_back(trace_kind);
       h->has_deep = h->has_deep || deep;
     }
-    h->deep_only_nests = h->has_deep && !any_deep_by_depth;
+    h->gen_levels = fs.generic_levels; h->gen_frames = fs.generic_frames;
+    if (h->tree_kids) h->prefer_wavefront = true;
     h->all_flat = true;
     for (const rptdev::Tree& tr : fs.trees) h->all_flat = h->all_flat && tr.root_leaf != 0;
     if (h->all_flat) { // does the scene fit a wave's share of LDS (160 KB per CU / 8 waves)?
@@ -1268,7 +1318,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
   try {
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    if (h->has_deep && !h->rays_in_kernel) {
+    if (h->has_deep && (!h->rays_in_kernel || h->tree_kids)) {
       // a scene with deep trees: the rays take the route a render's rays take — object by object, every deep tree with
       // its own queue, sort and persistent traversal (launch_query) — in pieces of at most 4 Mi rays
       const KernelTable* kt = table_for(precision_mode, h->ext_shapes);

@@ -12,11 +12,11 @@
 
 namespace rptdev {
 
-constexpr int KD_MAX_STACK = 32; // deepest kd-tree the traversal stack holds
-// KdTree<Box<dyn Bounded>> inside KdTree<Box<dyn Bounded>> ...: a group may sit this many levels below a top-level group
-// (kernels/shapes.inc kd_leaf: one instantiation of the group traversal per level)
+constexpr int KD_MAX_STACK = 32; // deepest kd-tree the fast traversals' stacks hold; deeper ones are walked by rpt_tree_generic
+// Light::Object whose shape is a group: Shape::sample descends through this many group levels at most (kernels/
+// sampling.inc keeps the chain for the way back in registers).  Geometry nests without limit (rpt_tree_generic).
 #ifndef RPT_MAX_NEST
-#define RPT_MAX_NEST 3
+#define RPT_MAX_NEST 7
 #endif
 constexpr int KD_LDS_LEVELS = 12;   // stack levels the persistent kernel keeps in LDS (rest: scratch)
 #ifndef RPT_KD_LDS_LEVELS_WF
@@ -90,7 +90,10 @@ struct alignas(16) Tree {
   uint64_t sample_zone; // rand 0.8 UniformInt zone for Uniform::from(0..num_prims): u64::MAX - (2^64 - n) % n,
                         // precomputed because a 64-bit modulo costs ~200 device instructions per light sample
   uint32_t mesh_kids;   // GROUP: some child is a MESH (a kd-tree of kd-trees): such an object is walked by the per-tree
-  uint32_t _pad2;       // kernels whatever its own depth (api.cpp)
+                        // kernels whatever its own depth (api.cpp)
+  uint32_t generic_only; // the tree of a top-level object that only rpt_tree_generic walks (a group among a group's
+                        // children, mesh children rpt_nest_trace does not take, a tree deeper than KD_MAX_STACK):
+                        // rpt_tree_enter hands it every ray
   double qlo[3];        // MESH: origin and step of the LeafBox fixed-point grid (coordinate = qlo + q * qscale)
   double qscale[3];
 };

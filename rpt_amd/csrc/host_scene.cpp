@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <future>
+#include <functional>
 #include <map>
 #include <thread>
 #include <cstdlib>
@@ -466,6 +467,7 @@ struct Flattener {
   std::string& err;
   std::map<std::pair<const void*, uint64_t>, int> mesh_cache; // shared meshes (Arc<Mesh>)
   const BuildOptions* build = nullptr;
+  bool light_shape = false; // the shape being flattened is a Light::Object's
 
   int add_tree(const std::vector<Box>& boxes, uint32_t prim_base) {
     KdBuild kb;
@@ -476,11 +478,7 @@ struct Flattener {
     }
     if (on_device) fs.trees_built_on_device++;
     else kd_build(boxes, kb);
-    if (kb.max_depth > (uint32_t)rptdev::KD_MAX_STACK) {
-      err = "kd-tree depth " + std::to_string(kb.max_depth) + " exceeds the device stack (" +
-            std::to_string(rptdev::KD_MAX_STACK) + ")";
-      return -1;
-    }
+    // (a tree deeper than KD_MAX_STACK is no error: the object it belongs to is walked by rpt_tree_generic, api.cpp)
     fs.max_tree_depth = std::max(fs.max_tree_depth, kb.max_depth);
     rptdev::Tree t;
     std::memset(&t, 0, sizeof(t));
@@ -600,11 +598,11 @@ struct Flattener {
         break;
       }
       case RPT_SHAPE_GROUP: {
-        // KdTree<Box<dyn Bounded>> forwards Bounded through Box (kdtree.rs:14-24), so a group can sit in a group;
-        // the device instantiates the group traversal once per nesting level (kernels/shapes.inc kd_leaf, RPT_MAX_NEST):
-        // a group inside a group inside ... down to that level; the reference's recursion has no limit
-        if (nesting > RPT_MAX_NEST) {
-          err = "KdTree<Box<dyn Bounded>> nested more than " + std::to_string(RPT_MAX_NEST + 1) + " levels deep";
+        // KdTree<Box<dyn Bounded>> forwards Bounded through Box (kdtree.rs:14-24), so a group can sit in a group, to
+        // any depth: rpt_tree_generic walks such an object (kernels/wavefront.inc).  Only Shape::sample keeps a limit:
+        // a LIGHT whose shape nests groups deeper than RPT_MAX_NEST is refused (kernels/sampling.inc sample_child)
+        if (light_shape && nesting > RPT_MAX_NEST) {
+          err = "Light::Object: KdTree<Box<dyn Bounded>> nested more than " + std::to_string(RPT_MAX_NEST + 1) + " levels deep";
           return RPTGPU_E_UNSUPPORTED_SHAPE;
         }
         if (nesting > 0) fs.nested_mesh = true;
@@ -711,7 +709,9 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const Bui
           return RPTGPU_E_UNIMPLEMENTED_SAMPLE;
         }
         rptdev::Inst in;
+        fl.light_shape = true;
         int rc = fl.fill_inst(l.object.shape, in, nullptr, nullptr, 0);
+        fl.light_shape = false;
         if (rc != RPTGPU_OK) return rc;
         dl.inst = (int32_t)fs.insts.size();
         fs.insts.push_back(in);
@@ -727,6 +727,37 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const Bui
   for (auto& g : fl.group_children) { // now place GROUP children and patch prim_base
     fs.trees[g.first].prim_base = (uint32_t)fs.insts.size();
     fs.insts.insert(fs.insts.end(), g.second.begin(), g.second.end());
+  }
+  // What rpt_tree_generic needs to walk any object of this scene (kernels/wavefront.inc): deferred far children — a
+  // tree of depth D defers at most D, plus those of the trees suspended above it — and one frame per tree child entered
+  {
+    std::vector<int> memo_levels(fs.trees.size(), -1), memo_frames(fs.trees.size(), -1);
+    std::function<void(int, bool)> need = [&](int t, bool group) {
+      if (memo_levels[t] >= 0) return;
+      uint32_t lv = 0, fr = 0;
+      fs.tree_kids[t] = 0;
+      if (group) {
+        const rptdev::Tree& tr = fs.trees[t];
+        for (uint32_t k = 0; k < tr.num_prims; k++) {
+          const rptdev::Inst& kid = fs.insts[tr.prim_base + k];
+          if (kid.kind != RPT_SHAPE_MESH && kid.kind != RPT_SHAPE_GROUP) continue;
+          fs.tree_kids[t] |= kid.kind == RPT_SHAPE_GROUP ? 2u : 1u;
+          need(kid.tree, kid.kind == RPT_SHAPE_GROUP);
+          lv = std::max(lv, (uint32_t)memo_levels[kid.tree]);
+          fr = std::max(fr, (uint32_t)memo_frames[kid.tree] + 1u);
+          if (fs.tree_kids[kid.tree] & 2u) fs.tree_kids[t] |= 2u;
+        }
+      }
+      memo_levels[t] = (int)(lv + fs.tree_depth[t] + 1u);
+      memo_frames[t] = (int)fr;
+    };
+    fs.tree_kids.assign(fs.trees.size(), 0);
+    for (const rptdev::Inst& in : fs.insts)
+      if (in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP) {
+        need(in.tree, in.kind == RPT_SHAPE_GROUP);
+        fs.generic_levels = std::max(fs.generic_levels, (uint32_t)memo_levels[in.tree]);
+        fs.generic_frames = std::max(fs.generic_frames, (uint32_t)memo_frames[in.tree]);
+      }
   }
   fs.lrec.resize(fs.refs.size()); // GROUP trees own ref slots too (unused records)
   fs.lbox.resize(fs.refs.size());

@@ -40,6 +40,8 @@ struct FlatScene {
   std::vector<rptdev::Inst> insts;
   std::vector<rptdev::Tree> trees;
   std::vector<uint32_t> tree_depth; // per tree: depth of its deepest leaf
+  std::vector<uint8_t> tree_kids;   // per tree (GROUP): bit 0 a child is a MESH, bit 1 a GROUP sits somewhere below it
+  uint32_t generic_levels = 0, generic_frames = 0; // heights of rpt_tree_generic's columns that hold any object of the scene
   std::vector<rptdev::KdNode> nodes;
   std::vector<uint32_t> refs;
   std::vector<rptdev::Tri> tris;

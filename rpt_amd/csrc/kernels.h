@@ -53,6 +53,13 @@ struct SortBufs {
 #endif
 // spill area of the traversal stack beyond the LDS levels: [KD_MAX_STACK - RPT_TT_LEVELS][threads] per array, one
 // column per thread of the traversal grid (api.cpp allocates it for scenes with deep trees)
+// rpt_tree_generic's pending work (kernels/wavefront.inc), one column per thread of ITS grid: deferred far children
+// (six face parameters, t_split, node) and the suspended leaves of the groups above the tree being walked
+struct GenericStack {
+  double* defer;  // [levels][8][threads]
+  double* frame;  // [frames][12][threads]
+  uint32_t threads, levels, frames;
+};
 struct StackSpill {
   uint32_t* node;
   double* ts;
@@ -64,6 +71,11 @@ struct StackSpill {
   // reads that row (and the slot from the query's queue) instead of gathering eight values from the path state's SoA
   // arrays.  The tree's queues hold positions, not slots.
   double* rays;
+  // rpt_tree_generic: its columns, the flag it raises if a scene outgrows them (api.cpp sizes them from the scene and
+  // checks the flag when the batch is done), and its grid when it takes a few handed-on rays / every ray of an object
+  GenericStack gen;
+  uint32_t* gen_overflow;
+  uint32_t gen_blocks_few, gen_blocks_all;
 };
 
 // accounting hook of launch_query: called with (ctx, kind, 0) before and (ctx, kind, 1) after the launches of

@@ -8,12 +8,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# kd-trees of kd-trees go through the per-tree kernels (rpt_nest_trace) only when a pass is large enough to pay for their
-# launches (api.cpp nest_min_paths, 6 Mi paths); the fixtures are a few thousand paths, so the tests ask for that route at
-# any size — test_small_passes_of_nest_scenes_walk_in_kernel covers the default
-os.environ.setdefault("RPTGPU_NEST_MIN_PATHS", "0")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -92,8 +92,8 @@ def nested_groups():
 
 
 def deep_nest():
-    """Groups four levels deep (the device's limit, RPT_MAX_NEST = 3 levels below a top-level group; the reference
-    recurses without one, kdtree.rs:14-24): every level placed by its own transform, a mesh, spheres, cubes and a monomial
+    """Groups four levels deep (what rounds 2-3 could take at most; `seven_nest` goes past any fixed limit, as the
+    reference's recursion does, kdtree.rs:14-24): every level placed by its own transform, a mesh, spheres, cubes and a monomial
     surface at the bottom, siblings at every level, and a lamp that is itself nested four deep (KdTree::sample at every
     level, kdtree.rs:138-143)."""
     scene = Scene()
@@ -119,6 +119,45 @@ def deep_nest():
     lamp = KdTree([b1.translate((-0.3, 3.2, 0.8)), sphere().scale((0.1, 0.1, 0.1)).translate((1.4, 3.1, 0.6))])
     scene.add(Light.Object(Object(lamp).material(Material.light((1.0, 0.95, 0.85), 50.0))))
     camera = Camera.look_at((0.6, 2.2, 6.8), (0.0, 0.4, 0.0), (0.0, 1.0, 0.0), 0.8)
+    return scene, camera
+
+
+def seven_nest():
+    """Groups SEVEN levels deep — past anything a fixed number of traversal instantiations would cover; the reference
+    recurses without a limit (kdtree.rs:14-24 forwards Bounded through Box) and the device walks such an object with
+    rpt_tree_generic.  Every level has its own transform and siblings of every kind (a mesh two, four and seven levels
+    down, spheres, cubes, a monomial surface), two of the groups are large enough to be real trees (>= 16 children), one
+    group is used twice (a shared subtree reached through different transforms), and one object is glass so that paths
+    continue INSIDE the nest.  The lamp is a group nested three deep (Shape::sample keeps a limit of eight)."""
+    scene = Scene()
+    scene.add(Object(plane((0.0, 1.0, 0.0), -1.0)).material(Material.diffuse(hex_color(0xA0A0A0))))
+    mesh = Mesh(scenes.knot_mesh(24, 6, seed=0x7E57))
+    g = KdTree([mesh.scale((0.45, 0.45, 0.45)), sphere().scale((0.18, 0.18, 0.18)).translate((0.7, 0.0, 0.0))] +
+               [sphere().scale((0.06, 0.06, 0.06)).translate((-0.8 + 0.1 * i, -0.45, 0.25)) for i in range(17)])       # level 6
+    for lvl in range(5, -1, -1):  # levels 5 .. 0, each wrapping the one below twice (once as it is, once transformed)
+        kids = [g.rotate_y(0.2 + 0.1 * lvl).translate((0.15 * lvl, 0.05 * lvl, 0.0)),
+                g.scale((0.55, 0.55, 0.55)).rotate_z(0.25).translate((1.1 + 0.1 * lvl, 0.5, -0.3 + 0.1 * lvl)),
+                (sphere() if lvl % 2 else cube().rotate_y(0.37).rotate_x(0.21)).scale((0.22, 0.22, 0.22)).translate((-1.0 - 0.1 * lvl, 0.1 * lvl, 0.5))]
+        if lvl == 3:
+            kids.append(mesh.scale((0.3, 0.3, 0.3)).translate((0.0, 1.0, 0.6)))
+            kids += [cube().scale((0.08, 0.08, 0.08)).rotate_y(0.3 * i + 0.1).rotate_x(0.15).translate((-1.2 + 0.15 * i, -0.6, 0.9)) for i in range(16)]
+        if lvl == 1:
+            kids.append(monomial_surface(0.6, 4.0).scale((0.35, 0.35, 0.35)).translate((-0.6, 0.9, 0.2)))
+        g = KdTree(kids)
+    scene.add(Object(g.scale((0.8, 0.8, 0.8)).translate((-0.3, 0.1, 0.0))).material(Material.specular(hex_color(0x7799BB), 0.3)))
+    inner = KdTree([KdTree([KdTree([mesh.scale((0.35, 0.35, 0.35)), sphere().scale((0.3, 0.3, 0.3)).translate((0.6, 0.0, 0.0))])
+                            .rotate_x(0.3), cube().rotate_y(0.45).rotate_z(0.2).scale((0.25, 0.25, 0.25)).translate((-0.6, 0.1, 0.0))]).translate((0.0, 0.2, 0.0)),
+                    sphere().scale((0.2, 0.2, 0.2)).translate((0.0, 0.9, 0.0))])
+    scene.add(Object(inner.translate((2.3, 0.0, 1.2))).material(Material.clear(1.5, 0.05)))
+    scene.add(Light.Ambient((0.02, 0.02, 0.02)))
+    scene.add(Light.Point((28.0, 28.0, 26.0), (1.5, 4.0, 4.5)))
+    scene.add(Light.Directional((0.3, 0.3, 0.35), (0.0, -0.6, -0.8)))  # a sun in a coordinate plane: a zero direction component in every
+    # shadow ray (no face of the scene is exactly parallel to it: bsdf would be 0/0 there, as in the reference)
+    lamp = KdTree([KdTree([KdTree([sphere().scale((0.12, 0.12, 0.12)).translate((0.3 * i, 0.0, 0.0)) for i in range(3)])
+                           .translate((0.0, 0.0, 0.2)), cube().scale((0.2, 0.05, 0.2)).translate((1.0, 0.0, 0.0))]).rotate_y(0.4),
+                   sphere().scale((0.1, 0.1, 0.1)).translate((-0.8, 0.1, 0.0))])
+    scene.add(Light.Object(Object(lamp.translate((0.0, 3.2, 0.8))).material(Material.light((1.0, 0.95, 0.85), 45.0))))
+    camera = Camera.look_at((0.8, 2.3, 6.6), (0.2, 0.4, 0.0), (0.0, 1.0, 0.0), 0.8)
     return scene, camera
 
 
@@ -222,6 +261,9 @@ def small(name):
     if name == "axis_sun":
         s, c = axis_sun()
         return s, c, make_params(64, 40, 4, 4, seed=121)
+    if name == "seven_nest":
+        s, c = seven_nest()
+        return s, c, make_params(64, 40, 5, 4, seed=123)
     # the same scenes at 256x144 with 32 spp: ~10^6 samples each, so that draw sequences a 64x36 frame at 4 spp
     # hardly ever produces (long rejection loops, TIR, gen_range redraws, deep clamp chains) do occur
     if name == "cornell_hi":
@@ -236,4 +278,4 @@ def small(name):
 HI_NAMES = ["cornell_hi", "coverage_hi"]
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
          "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots", "nested_groups",
-         "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video", "axis_sun", "deep_nest"]
+         "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video", "axis_sun", "deep_nest", "seven_nest"]

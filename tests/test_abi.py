@@ -62,24 +62,30 @@ def test_unsupported_shapes_rejected_at_scene_create_without_gpu():
         rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_UNIMPLEMENTED_SAMPLE  # plane.rs:34-36 unimplemented!()
 
-    # groups inside groups are in the closed set down to four levels (kdtree.rs:14-24; RPT_MAX_NEST); a fifth is not
-    scene = rpt_amd.Scene()
+    # groups inside groups to ANY depth, as in the reference (kdtree.rs:14-24): flattening succeeds, only the device is missing
     inner = rpt_amd.KdTree([rpt_amd.sphere().translate((0, 0, 0))])
-    scene.add(rpt_amd.Object(rpt_amd.KdTree([inner, rpt_amd.sphere()])))
+    g = inner
+    for _ in range(12):
+        g = rpt_amd.KdTree([g, rpt_amd.sphere(), rpt_amd.cube()])
+    scene = rpt_amd.Scene()
+    scene.add(rpt_amd.Object(g))
     with pytest.raises(rpt_amd.RptGpuError) as e:
         rpt_amd.GpuScene(scene)
-    assert e.value.code == _abi.RPTGPU_E_NO_DEVICE   # flattening succeeded; only the device is missing here
+    assert e.value.code == _abi.RPTGPU_E_NO_DEVICE
+    # ... except as the shape of a Light::Object: Shape::sample keeps its chain of groups in registers, eight levels
+    lamp = inner
+    for _ in range(7):
+        lamp = rpt_amd.KdTree([lamp, rpt_amd.sphere()])
     scene = rpt_amd.Scene()
-    four = rpt_amd.KdTree([rpt_amd.KdTree([rpt_amd.KdTree([inner, rpt_amd.cube()]), rpt_amd.sphere()]), rpt_amd.cube()])
-    scene.add(rpt_amd.Object(four))
+    scene.add(rpt_amd.Light.Object(rpt_amd.Object(lamp)))
     with pytest.raises(rpt_amd.RptGpuError) as e:
         rpt_amd.GpuScene(scene)
     assert e.value.code == _abi.RPTGPU_E_NO_DEVICE
     scene = rpt_amd.Scene()
-    scene.add(rpt_amd.Object(rpt_amd.KdTree([four, rpt_amd.sphere()])))
+    scene.add(rpt_amd.Light.Object(rpt_amd.Object(rpt_amd.KdTree([lamp, rpt_amd.cube()]))))
     with pytest.raises(rpt_amd.RptGpuError) as e:
         rpt_amd.GpuScene(scene)
-    assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE
+    assert e.value.code == _abi.RPTGPU_E_UNSUPPORTED_SHAPE and "Light::Object" in str(e.value)
 
     scene = rpt_amd.Scene()  # MonomialSurface: only exp = 4 (monomial_surface.rs:10), at top level or as a tree child
     scene.add(rpt_amd.Object(rpt_amd.monomial_surface(1.0, 3.0)))

@@ -24,6 +24,10 @@ FULL = {
     "fractal_spheres": (scenes.fractal_spheres, 128, 2),  # C4: 3840x2160, B=8
     "wine_glass": (scenes.wine_glass, 128, 2),            # C5 (mesh variant): 3840x2160, B=16
     "glass": (scenes.glass, 256, 2),                      # C5 (sphere variant): 3840x2160, B=16
+    # examples/fractal_teapots.rs in full (937 placed copies of one mesh under five group trees), 800x600, with 8 bounces
+    # instead of the example's 0 so that shadow and bounce rays walk the nests too.  Back in the suite since round 4: the
+    # nested traversal's call frames (14 KB of scratch per lane, a runtime slow path afterwards) are gone
+    "fractal_teapots": (lambda: (lambda s, c, d: (s, c, dict(d, max_bounces=8)))(*scenes.fractal_teapots()), 16, 2),
 }
 
 
