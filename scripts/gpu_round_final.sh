@@ -1,14 +1,14 @@
 #!/bin/bash
-# evidence of round 3 (run through gpurun from the repo root):
+# the evidence of a round (run through gpurun from the repo root):  TAG=r04 bash scripts/gpu_round_final.sh ["scene:trace_spp:pmc_spp ..."]
 #   1. the GPU test suite
 #   2. the DEFAULT bench command (what the driver runs): headline C2 + the other BASELINE configs + live counters
 #   3. rocprofv3 --kernel-trace --stats of the bench command per scene + PMC passes, summarised ON the box (the rocpd
 #      databases do not travel: 64 MiB limit) into gpurun_out/r03final/profiles/
 #   4. per-phase lane-occupancy tables from the -DRPT_PROF build (rpt_amd/lib/librptgpu_prof.so, if present)
-#   bash scripts/gpu_round3_final.sh ["scene:trace_spp:pmc_spp ..."]
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
-O=gpurun_out/r03final; mkdir -p $O
+TAG=${TAG:-r04}
+O=gpurun_out/${TAG}final; mkdir -p $O
 export TMPDIR=/tmp
 export RPT_PROFILE_DST=$REPO/$O/profiles
 mkdir -p $RPT_PROFILE_DST
@@ -17,9 +17,9 @@ timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; ech
 LIST=${1:-"cornell:0:512 dragon:32:16 wine_glass:8:4 fractal_spheres:8:4 room23:64:64"}
 for item in $LIST; do
   IFS=: read sc tspp pspp <<< "$item"
-  bash scripts/profile.sh r03 $sc $tspp $pspp "--no-live-pmc" > $O/profile_$sc.log 2>&1
-  python scripts/summarize_profile.py r03 $sc > $O/summary_$sc.txt 2>&1
-  rm -rf gpurun_out/prof_r03_$sc
+  bash scripts/profile.sh $TAG $sc $tspp $pspp "--no-live-pmc" > $O/profile_$sc.log 2>&1
+  python scripts/summarize_profile.py $TAG $sc > $O/summary_$sc.txt 2>&1
+  rm -rf gpurun_out/prof_${TAG}_$sc
 done
 P=$PWD/rpt_amd/lib/librptgpu_prof.so
 if [ -f $P ]; then
@@ -31,9 +31,10 @@ if [ -f $P ]; then
 fi
 timeout 300 python bench.py --scene simple_video > $O/simple_video.json 2>/dev/null
 timeout 300 python bench.py --scene fractal_teapots --bounces 8 --spp 64 --steps 2 --warmup 1 --no-live-pmc > $O/fractal_teapots_b8.json 2>/dev/null
-python - <<'PY'
+TAG=$TAG python - <<'PY'
 import json
-d=json.load(open("gpurun_out/r03final/bench_default.json"))
+import os
+d=json.load(open("gpurun_out/%sfinal/bench_default.json" % os.environ.get("TAG", "r04")))
 r=d["roofline"]
 print("C2 %.1f Msamples/s  %.1f ms/step  frac %.3f (valu_busy %.3f x lanes %.1f/64)  hbm_frac %s  acc_frac %.2f  cpu %.2f  src: %s" % (d["value"], d["ms_per_step"], r.get("frac") or 0, r.get("valu_busy") or 0, r.get("lanes_active") or 0, r.get("hbm_frac"), r.get("accounting_frac") or 0, (d.get("cpu_baseline") or {}).get("value",0), (r.get("pmc_source") or "")[:40]))
 for o in d.get("other_configs",[]):
