@@ -504,6 +504,8 @@ bool kd_build_device(const std::vector<Box>& boxes, KdBuild& out, int device, st
   hipStream_t st = nullptr;
   uint32_t* pinned = nullptr;
   bool ok = false;
+  int prev_device = -1; // the caller's current device is put back: a library call must not move it
+  (void)hipGetDevice(&prev_device);
   try {
     KD_TRY(hipSetDevice(device));
     KD_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -531,9 +533,16 @@ bool kd_build_device(const std::vector<Box>& boxes, KdBuild& out, int device, st
     (void)hipGetLastError();
     why = std::string(e.what) + ": " + hipGetErrorString(e.e);
     ok = false;
+  } catch (const std::exception& e) { // (bad_alloc of a host vector: the stream and the pinned buffer are released below)
+    why = std::string("device kd build: ") + e.what();
+    ok = false;
+  } catch (...) {
+    why = "device kd build: unexpected exception";
+    ok = false;
   }
   if (pinned) (void)hipHostFree(pinned);
   if (st) (void)hipStreamDestroy(st);
+  if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
   return ok;
 }
 
