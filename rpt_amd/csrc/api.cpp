@@ -1180,11 +1180,12 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
   const char* mode_env = std::getenv("RPTGPU_COLLECTIVE");
   bool gather = !(mode_env && std::strcmp(mode_env, "reduce") == 0);
   if (world > 1 && gather && !(rc_lib->Send && rc_lib->Recv && rc_lib->GroupStart && rc_lib->GroupEnd)) gather = false;
+  if (!h->comm) gather = false; // no communicator: a plain render straight into the frame (a 1-rank communicator still packs and places)
   try {
     HIP_TRY(hipSetDevice(h->device));
     for (auto& e : h->ev)
       if (!e) HIP_TRY(hipEventCreate(&e));
-    if (rank == root) h->frame32_sum.alloc(n);
+    if (rank == root && (gather || world > 1)) h->frame32_sum.alloc(n);
     if (gather) {
       ensure_partition(h, p);
       h->packed32.alloc(std::max<uint64_t>(1, (uint64_t)h->npix * 3));
