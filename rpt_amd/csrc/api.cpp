@@ -899,8 +899,8 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         lay.off_mat = (uint32_t)off;  off = up16(off + (uint64_t)fs.num_objects * sizeof(rptdev::Material));
         lay.off_leaf = (uint32_t)off; off = up16(off + (uint64_t)fs.num_objects * 16);
       };
-      assign(true);
-      if (off + 12 * 64 * sizeof(double) > WAVE_LDS || std::getenv("RPTGPU_FLAT_TRIS_GLOBAL")) assign(false); // (room for the plane table)
+      assign(true); // (rpt_paths<KdFlat>: that instantiation also stashes camera rays in LDS)
+      if (off + 12 * 64 * sizeof(double) + RPT_PATHS_STASH_LDS > WAVE_LDS || std::getenv("RPTGPU_FLAT_TRIS_GLOBAL")) assign(false); // (room for the plane table)
       // shared slab quotients: distinct plane coordinates per axis over the untransformed meshes (bitwise
       // distinct: -0.0 and 0.0 give differently signed zeros), at most 4 per axis or the feature stays off
       std::vector<double> planes(12, 0.0);

@@ -15,6 +15,8 @@ static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * m
 // LDS of one wave of rpt_paths: 160 KB per CU / (2 waves per SIMD x 4 SIMDs); the fold walker's static share of it
 #define RPT_PATHS_WAVE_LDS 20480u
 #define RPT_PATHS_WALKER_LDS 2560u
+// rpt_paths<KdFlat> (a flat scene WITH its triangles in LDS) also keeps the lanes' stashed camera rays there
+#define RPT_PATHS_STASH_LDS 4864u
 
 // layout of the flat path kernel's dynamic LDS (byte offsets; lrec at 0), see kernels.inc
 struct FlatLayout {
