@@ -542,7 +542,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       const bool flat = h->all_flat && !h->dscene.force_general;
       FlatLayout lay = flat ? h->flat_layout : FlatLayout{};
       const uint32_t flat_lds = lay.off_end;
-      int per_cu = kt->paths_max_blocks_per_cu(flat, flat_lds);
+      int per_cu = kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds);
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
       nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
       uint64_t nthreads = (uint64_t)nblocks * 64;

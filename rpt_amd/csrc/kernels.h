@@ -105,7 +105,7 @@ struct KernelTable {
   void (*scatter_f32)(hipStream_t, const float* src, const uint32_t* pixels, uint32_t n, float* dst);
   void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
   // persistent per-pixel kernel: resident 64-thread blocks per CU, and the launch
-  int (*paths_max_blocks_per_cu)(bool flat, uint32_t lds_bytes);
+  int (*paths_max_blocks_per_cu)(const FlatLayout* flat /* null: not a flat scene */, uint32_t lds_bytes);
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
                 uint32_t chunk, uint32_t n_items, uint32_t nblocks, const FlatLayout& lay, bool flat, uint32_t lds_bytes);
