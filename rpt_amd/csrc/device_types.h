@@ -48,13 +48,15 @@ struct alignas(16) TriX {
   double d00, d01, d11, denom;
 };
 
-// Conservative bounding box of one leaf entry of a MESH tree, in leaf order like TriX: six 16-bit fixed-point
+// Conservative bounding box of one leaf entry of a MESH tree, in leaf order like TriX: 16-bit fixed-point
 // coordinates relative to the tree's bounds (Tree::qlo / qscale), minima rounded down and maxima rounded up by
-// one step more than needed.  16 B = ONE per-lane gather.  It is a FILTER in front of Triangle::intersect: a
+// one step more than needed, stored per axis as CENTRE and HALF-EXTENT — the slab interval of an axis is then
+// t(centre) -+ half * |a|, whatever the sign of the direction: one fma and one packed fma instead of two fma's,
+// a min and a max.  16 B = ONE per-lane gather.  It is a FILTER in front of Triangle::intersect: a
 // ray that misses the box (in the window [t_min, record.time]) cannot be accepted by the exact test, so skipping
 // the exact test changes nothing (kernels/shapes.inc, leaf_box_pass).
 struct alignas(16) LeafBox {
-  uint32_t w[4]; // w0 = min.x | min.y << 16, w1 = min.z | max.x << 16, w2 = max.y | max.z << 16, w3 unused
+  uint32_t w[4]; // w[k] = centre_k | half_k << 16 for k = x, y, z; w3: 1 = the whole grid (never filtered)
 };
 
 // A placed shape: a top-level scene object, a light's shape, or a child of a GROUP tree.

@@ -357,8 +357,15 @@ rptdev::LeafBox quantise_box(const Box& b, const double* qlo, const double* qsca
     q[3 + k] = (uint32_t)std::fmin(std::fmax(c, 0.0), 65535.0);
   }
   if (full) { q[0] = q[1] = q[2] = 0; q[3] = q[4] = q[5] = 65535; }
+  // stored per axis as centre and half-extent (device_types.h): c = floor of the middle, h = hi - c >= c - lo, so
+  // [c - h, c + h] contains [lo, hi] and is at most one step wider on the low side (c - h may be -1: the decode is
+  // arithmetic, nothing clamps it)
   rptdev::LeafBox lb;
-  lb.w[0] = q[0] | (q[1] << 16); lb.w[1] = q[2] | (q[3] << 16); lb.w[2] = q[4] | (q[5] << 16); lb.w[3] = full ? 1u : 0u;
+  for (int k = 0; k < 3; k++) {
+    const uint32_t c = (q[k] + q[3 + k]) >> 1, h = q[3 + k] - c;
+    lb.w[k] = c | (h << 16);
+  }
+  lb.w[3] = full ? 1u : 0u;
   return lb;
 }
 void grid_over(const double* bounds, double* qlo, double* qscale) {
