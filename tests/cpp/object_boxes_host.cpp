@@ -38,8 +38,12 @@ int main() {
               fs.obj_grid[4], fs.obj_grid[5]);
   for (size_t i = 0; i < fs.obj_lbox.size(); i++) {
     const rptdev::LeafBox& b = fs.obj_lbox[i];
-    unsigned q[6] = {b.w[0] & 0xffffu, b.w[0] >> 16, b.w[1] & 0xffffu, b.w[1] >> 16, b.w[2] & 0xffffu, b.w[2] >> 16};
-    std::printf("box %zu full %u q %u %u %u %u %u %u\n", i, b.w[3], q[0], q[1], q[2], q[3], q[4], q[5]);
+    int q[6]; // decoded as the device does: centre -+ half-extent per axis (device_types.h LeafBox)
+    for (int k = 0; k < 3; k++) {
+      const int c = (int)(b.w[k] & 0xffffu), e = (int)(b.w[k] >> 16);
+      q[k] = c - e; q[3 + k] = c + e;
+    }
+    std::printf("box %zu full %u q %d %d %d %d %d %d\n", i, b.w[3], q[0], q[1], q[2], q[3], q[4], q[5]);
   }
   // a group among the objects: the filtered walk does not dispatch it, the scene is not filtered at all
   std::vector<Shape> kids = {sphere(), cube().translate({2.0, 0.0, 0.0})};
