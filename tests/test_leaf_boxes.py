@@ -42,7 +42,8 @@ def outward(x, sign):
 def box_pass(q, scale, lo, o, d, t_lo, t_hi, far=1e12):
     """boxray_make + box_window + leaf_box_pass for pairs (q[i], ray i); returns (pass, filter_on).  The device evaluates
     the slabs in f32 with fmaf, counted from t0 = max(root slab entry, 0); numpy has no fmaf: q * a is exact in f64
-    (16 x 24 bits), so f64 add + one rounding to f32 differs from it only in rare double-rounding ties."""
+    (16 x 24 bits), so f64 add + one rounding to f32 differs from it only in rare double-rounding ties.  q arrives as
+    (lo, hi) grid coordinates; the stored form — centre and half-extent — is derived here as the host derives it."""
     with np.errstate(all="ignore"):
         z = d == 0                      # axes the ray does not move along: "is the origin inside the box on that axis"
         r = 1.0 / d
@@ -58,9 +59,15 @@ def box_pass(q, scale, lo, o, d, t_lo, t_hi, far=1e12):
                       & (np.abs(u) < far * np.abs(a)))
         on = ~z.all(axis=1) & ok.all(axis=1) & (np.abs(t0) < 1e300)
         a32, b32 = a.astype(np.float32), b.astype(np.float32)
-        t0_ = (q[:, 0:3] * a32.astype(np.float64) + b32.astype(np.float64)).astype(np.float32)
-        t1_ = (q[:, 3:6] * a32.astype(np.float64) + b32.astype(np.float64)).astype(np.float32)
-        near, far = np.fmin(t0_, t1_), np.fmax(t0_, t1_)
+        # stored as centre and half-extent (quantise_box): c = floor((lo + hi) / 2), h = hi - c; the slab ends of an axis
+        # are t(c) -+ h |a|: one fma for the centre, one (packed) fma for both ends, whatever the direction's sign
+        qc = np.floor((q[:, 0:3] + q[:, 3:6]) / 2.0)
+        qh = q[:, 3:6] - qc
+        assert (qc - qh <= q[:, 0:3]).all() and (qc - qh >= q[:, 0:3] - 1.0).all() and qh.max() <= 32768.0
+        tc = (qc * a32.astype(np.float64) + b32.astype(np.float64)).astype(np.float32)
+        h32 = np.abs(a32).astype(np.float64)
+        near = (tc.astype(np.float64) - qh * h32).astype(np.float32)
+        far = (tc.astype(np.float64) + qh * h32).astype(np.float32)
         tl = np.fmax(np.fmax(near[:, 0], near[:, 1]), near[:, 2])
         th = np.fmin(np.fmin(far[:, 0], far[:, 1]), far[:, 2])
         wl = outward(np.broadcast_to(np.asarray(t_lo, dtype=np.float64), t0.shape) - t0, -1.0)
