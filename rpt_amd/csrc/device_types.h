@@ -55,6 +55,9 @@ struct alignas(16) TriX {
 // a min and a max.  16 B = ONE per-lane gather.  It is a FILTER in front of Triangle::intersect: a
 // ray that misses the box (in the window [t_min, record.time]) cannot be accepted by the exact test, so skipping
 // the exact test changes nothing (kernels/shapes.inc, leaf_box_pass).
+// entries of padding at the end of the LeafBox array: the filter's batches over a GROUP leaf (4 boxes) read unclamped — one
+// address and immediates; the bits past the leaf's end are masked out
+#define RPT_LBOX_PAD 16
 struct alignas(16) LeafBox {
   uint32_t w[4]; // w[k] = centre_k | half_k << 16 for k = x, y, z; w3: 1 = the whole grid (never filtered)
 };

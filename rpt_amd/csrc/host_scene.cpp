@@ -767,7 +767,9 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const Bui
       }
   }
   fs.lrec.resize(fs.refs.size()); // GROUP trees own ref slots too (unused records)
-  fs.lbox.resize(fs.refs.size());
+  // the box batches of the leaf filter read a whole batch from the leaf's first entry on, unclamped — entries past the
+  // leaf's end are masked out, not skipped — so the array ends with a batch of padding (kernels/shapes.inc)
+  fs.lbox.resize(fs.refs.size() + RPT_LBOX_PAD);
   fs.env_kind = sc.environment.kind;
   std::memcpy(fs.env_color, sc.environment.color, sizeof(fs.env_color));
   if (sc.environment.kind == RPT_ENV_HDRI) {
