@@ -194,6 +194,7 @@ struct rptgpu_scene {
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
   int sort_mode = -1;              // RPTGPU_SORT_RAYS: 0 never, 1 every deep tree, default: by footprint
   uint64_t sort_min_bytes = 8ull << 20;  // RPTGPU_SORT_MIN_BYTES: nodes + leaf records of a tree whose rays are worth sorting
+  uint64_t sort_shadow_min_bytes = 32ull << 20; // RPTGPU_SORT_SHADOW_MIN_BYTES: ... whose SHADOW rays are, too
   DevBuf<uint32_t> sort_kin, sort_kout, sort_vin;
   DevBuf<uint8_t> sort_tmp;
   SortBufs sort_bufs{};
@@ -817,6 +818,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     if (const char* e = std::getenv("RPTGPU_RAYS_IN_KERNEL")) h->rays_in_kernel = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_RAYS")) h->sort_mode = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_MIN_BYTES")) h->sort_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
+    if (const char* e = std::getenv("RPTGPU_SORT_SHADOW_MIN_BYTES")) h->sort_shadow_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
     for (int i = 0; i < fs.num_objects; i++) {
       const rptdev::Inst& in = fs.insts[i];
       bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
@@ -835,7 +837,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       // records) 144 -> 172 Msamples/s, 16k-triangle glass (17 MB) 469 -> 528, a 25k-triangle mesh under few bounces
       // (25 MB) 781 -> 766, two 768-triangle meshes (0.6 MB) 4243 -> 3248: the sort sorts EVERY ray of the depth, the
       // gain grows with the work of the rays that enter — so by size, with the threshold well below the glass
-      bool sort = false;
+      bool sort = false, sort_shadow = false;
       if (deep) {
         const rptdev::Tree& tr = fs.trees[in.tree];
         uint64_t next_node = (size_t)in.tree + 1 < fs.trees.size() ? fs.trees[in.tree + 1].node_base : fs.nodes.size();
@@ -843,6 +845,10 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         uint64_t bytes = (next_node - tr.node_base) * sizeof(rptdev::KdNode) +
                          (next_ref - tr.ref_base) * (sizeof(uint32_t) + (in.kind == RPT_SHAPE_MESH ? sizeof(rptdev::TriX) : 0));
         sort = h->sort_mode == 1 || (h->sort_mode < 0 && bytes >= h->sort_min_bytes);
+        // shadow rays point at ONE light from surfaces that the closest-hit pass just visited in sorted order: for a tree
+        // that is not many times the L2s their sort costs more than it gives (16k-triangle glass, ~10 MB: shadow stage
+        // 47.7 -> 42.8 ms per two steps without it; 100k-triangle mesh, ~60 MB: 137 -> 180)
+        sort_shadow = sort && (h->sort_mode == 1 || bytes >= h->sort_shadow_min_bytes);
       }
       // which traversal kernel of the per-tree pipeline: 1 rpt_tree_trace<TRIS>, 0 rpt_tree_trace over a group of simple
       // shapes, 2 a group with mesh children whose two regular levels fit one traversal stack: rpt_nest_trace
@@ -868,13 +874,15 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
         trace_kind = 3;
         fs.trees[in.tree].generic_only = 1u;
         sort = false;
+        sort_shadow = false;
       }
       h->sort_rays = h->sort_rays || sort;
       // obj_deep: 0 in-kernel; 1 per-tree; 2 per-tree with the ray sort; +4: every ray of it goes through rpt_tree_generic
       // (an irregular tree, an object only that kernel is built for)
       const bool all_generic = deep && (generic_only || !fs.trees[in.tree].regular);
       h->gen_all = h->gen_all || all_generic;
-      h->obj_deep.push_back(deep ? (uint8_t)((sort ? 2 : 1) | (all_generic ? 4 : 0)) : 0);
+      // +8: the sort serves the closest-hit query only
+      h->obj_deep.push_back(deep ? (uint8_t)((sort ? 2 : 1) | (all_generic ? 4 : 0) | (sort && !sort_shadow ? 8 : 0)) : 0);
       h->obj_tris.push_back(trace_kind);
       h->has_deep = h->has_deep || deep;
     }
