@@ -614,9 +614,12 @@ std::unique_ptr<KdNode> construct(const std::vector<BBox>& all, std::vector<size
     zs.push_back(b.p_min.z); zs.push_back(b.p_max.z);
     bboxs.push_back(b);
   }
-  std::sort(xs.begin(), xs.end());
-  std::sort(ys.begin(), ys.end());
-  std::sort(zs.begin(), zs.end());
+  // kdtree.rs:251-254: `sort_by(partial_cmp)` is a STABLE sort under which -0.0 and +0.0 are equal — entries that
+  // compare equal keep the order they were pushed in (per index: p_min, p_max).  It matters in one case: zeros of both
+  // signs around the middle of the array decide the SIGN of a zero median ((-0 + -0) / 2 = -0, every other pair +0).
+  std::stable_sort(xs.begin(), xs.end());
+  std::stable_sort(ys.begin(), ys.end());
+  std::stable_sort(zs.begin(), zs.end());
   double m[3] = {median(xs), median(ys), median(zs)};
   auto partition_score = [&](int dim, double value) {
     size_t left = 0, right = 0;

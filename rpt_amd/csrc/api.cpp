@@ -194,6 +194,7 @@ struct rptgpu_scene {
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
   int sort_mode = -1;              // RPTGPU_SORT_RAYS: 0 never, 1 every deep tree, default: by footprint
   uint64_t sort_min_bytes = 8ull << 20;  // RPTGPU_SORT_MIN_BYTES: nodes + leaf records of a tree whose rays are worth sorting
+  QueryTuning qtune{0u, 1u << 20};  // launch_query's counter-set toggle; RPTGPU_SORT_MIN_RAYS: queries of fewer rays are not sorted
   uint64_t sort_shadow_min_bytes = 32ull << 20; // RPTGPU_SORT_SHADOW_MIN_BYTES: ... whose SHADOW rays are, too
   DevBuf<uint32_t> sort_kin, sort_kout, sort_vin;
   DevBuf<uint8_t> sort_tmp;
@@ -392,17 +393,17 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   h->shadow.alloc((uint64_t)nl * rptdev::SHADOW_FIELDS * cap);
   h->queue_a.alloc(cap);
   h->queue_b.alloc(cap);
-  h->counters.alloc(2 + (size_t)nl); // [0] next-depth paths, [1] hits, [2 + l] shadow rays queued for light l
+  h->counters.alloc(2 * (2 + (size_t)nl)); // two sets (rpt_shade clears the other one) of: [0] next-depth paths, [1] hits, [2 + l] shadow rays queued for light l
   h->shadow_q.release();
   h->shadow_q.alloc((uint64_t)nl * cap); // per light: the paths that cast a shadow ray towards it at the current depth
   h->srt.release();
   h->srt.alloc((uint64_t)nl * cap);      // per light and path: record.time of the shadow ray (rpt_shadow_sum reads it)
   if (h->has_deep) {
     h->tq.alloc(3 * cap); // a tree's ray queue | its rays with a zero direction component | those handed to the general form
-    h->tq_ctr.alloc(5);
+    h->tq_ctr.alloc(16); // two sets of a tree's five counters, eight words apart (launch_query, QueryTuning::ctr_set)
     { // the traversal grid's stack spill area: one column per thread, as high as the scene's deepest tree (at least KD_MAX_STACK) less the LDS levels
       const uint64_t threads = (uint64_t)std::max(1, h->num_cus * 4) / 4 * RPT_TT_WAVES * 256;
-      const uint64_t levels = (uint64_t)(std::max<uint32_t>((uint32_t)rptdev::KD_MAX_STACK, h->max_tree_depth + 1u) - RPT_TT_LEVELS);
+      const uint64_t levels = (uint64_t)(std::max<uint32_t>((uint32_t)rptdev::KD_MAX_STACK, h->max_tree_depth + 1u) - RPT_TT_LEVELS_MIN);
       h->spill_node.alloc(levels * threads); h->spill_ts.alloc(levels * threads); h->spill_bmax.alloc(levels * threads);
       uint32_t zeros_common = 0; // every shadow ray towards an axis-parallel directional light has a zero component
       for (const rptdev::Light& l : h->host_lights)
@@ -625,6 +626,15 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
       rptdev::Camera cam = make_camera(*camera);
       const bool any_lights = h->dscene.num_lights > 0;
+      // the counter sets the kernels clear for each other start cleared (one memset per render, not one per depth and
+      // per tree and query: 102 of the wine glass's 354 fills per step)
+      const uint32_t nctr = 2u + (uint32_t)h->dscene.num_lights;
+      HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * (size_t)nctr * sizeof(uint32_t), st));
+      uint32_t cset = 0;
+      if (h->has_deep) {
+        HIP_TRY(hipMemsetAsync(h->tq_ctr.p, 0, 16 * sizeof(uint32_t), st));
+        h->qtune.ctr_set = 0;
+      }
       QueryMarks qm(h, prof);
       const QueryHook qhook{query_mark, &qm};
 
@@ -646,15 +656,17 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           { Bracket b(h, RPT_K_EXTEND, prof);
             if (by_object)
               kt->query(st, h->dscene, ps, queue, n_active, -1, nullptr, nullptr, h->obj_deep.data(), h->obj_tris.data(),
-                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill);
+                        h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill, &h->qtune);
             else
               kt->extend(st, h->dscene, ps, queue, n_active);
             b.done(); }
           h->stats.extend_rays += n_active;
           const int nl = h->dscene.num_lights;
-          HIP_TRY(hipMemsetAsync(h->counters.p, 0, (2 + (size_t)nl) * sizeof(uint32_t), st));
+          uint32_t* const ctrs = h->counters.p + (size_t)cset * nctr;       // this depth's counters (cleared by the depth before)
+          uint32_t* const ctrs_next = h->counters.p + (size_t)(cset ^ 1u) * nctr;
+          cset ^= 1u;
           { Bracket b(h, RPT_K_SHADE, prof);
-            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, h->counters.p, h->shadow_q.p); b.done(); }
+            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, ctrs, h->shadow_q.p, ctrs_next, nctr); b.done(); }
           if (any_lights) {
             // the visibility queries run over rpt_shade's per-light shadow-ray queues; their lengths stay on the device
             // (the launches are sized for n_active, the host's bound) and are read back with the depth's other counters
@@ -662,19 +674,19 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
             if (by_object) {
               for (int l = 0; l < nl; l++)
                 if (h->light_casts[l])
-                  kt->query(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, n_active, l, h->srt.p, h->counters.p + 2 + l, h->obj_deep.data(), h->obj_tris.data(),
-                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill);
+                  kt->query(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, n_active, l, h->srt.p, ctrs + 2 + l, h->obj_deep.data(), h->obj_tris.data(),
+                            h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill, &h->qtune);
             } else {
               for (int l = 0; l < nl; l++)
                 if (h->light_casts[l])
-                  kt->shadow_rays(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, h->counters.p + 2 + l, n_active, l, h->srt.p);
+                  kt->shadow_rays(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, ctrs + 2 + l, n_active, l, h->srt.p);
             }
             kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
             b.done();
           }
           h->cnt_host.resize(2 + (size_t)nl);
           uint32_t* cnt = h->cnt_host.data();
-          HIP_TRY(hipMemcpyAsync(cnt, h->counters.p, (2 + (size_t)nl) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipMemcpyAsync(cnt, ctrs, (2 + (size_t)nl) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
           for (int l = 0; l < nl; l++) h->stats.shadow_rays_traced += cnt[2 + l];
           if (prof && h->pending.size() >= 256) drain_events(h); // the stream is idle here: cheap
@@ -819,6 +831,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     if (const char* e = std::getenv("RPTGPU_SORT_RAYS")) h->sort_mode = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RPTGPU_SORT_MIN_BYTES")) h->sort_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
     if (const char* e = std::getenv("RPTGPU_SORT_SHADOW_MIN_BYTES")) h->sort_shadow_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
+    if (const char* e = std::getenv("RPTGPU_SORT_MIN_RAYS")) h->qtune.sort_min_rays = (uint32_t)std::max(0ll, std::min(std::atoll(e), 0xffffffffll));
     for (int i = 0; i < fs.num_objects; i++) {
       const rptdev::Inst& in = fs.insts[i];
       bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
@@ -1347,8 +1360,10 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
           }
         for (int k = 0; k < 6; k++)
           HIP_TRY(hipMemcpyAsync(ps.ray + (uint64_t)k * ps.cap, soa.data() + (uint64_t)k * m, m * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(h->tq_ctr.p, 0, 16 * sizeof(uint32_t), st));
+        h->qtune.ctr_set = 0;
         kt->query(st, h->dscene, ps, nullptr, (uint32_t)m, -1, nullptr, nullptr, h->obj_deep.data(), h->obj_tris.data(),
-                  h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, nullptr, &h->spill);
+                  h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, nullptr, &h->spill, &h->qtune);
         HIP_TRY(hipGetLastError());
         for (int k = 0; k < 4; k++)
           HIP_TRY(hipMemcpyAsync(hit.data() + (uint64_t)k * m, ps.hit + (uint64_t)k * ps.cap, m * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -75,14 +75,38 @@ constexpr double SCORE_THRESHOLD = 0.85; // kdtree.rs:6
 
 // median of the multiset `v` as `median(&sorted)` (kdtree.rs:347-355) would return it, without
 // the full sort the reference does: only the two middle order statistics matter.
-double median_of(std::vector<double>& v) {
+// The reference's sort is STABLE and compares -0.0 == +0.0 (kdtree.rs:251-254): among equal entries the pushed order
+// (per index: p_min, p_max) survives.  Only one thing can see it — the SIGN of a zero median when both middle entries
+// are zeros: (-0 + -0) / 2 = -0, any other pair of zeros +0.  `both_zero` reports that case; median_zero_sign then
+// finds WHICH two pushed entries the stable sort puts in the middle.
+double median_of(std::vector<double>& v, bool& both_zero) {
   size_t n = v.size();
   size_t mid = n / 2;
   std::nth_element(v.begin(), v.begin() + mid, v.end());
   double hi = v[mid];
+  both_zero = false;
   if (n % 2 == 1) return hi;
   double lo = *std::max_element(v.begin(), v.begin() + mid);
+  both_zero = hi == 0.0 && lo == 0.0;
   return (hi + lo) / 2.0;
+}
+// the median (a zero) of the 2n pushed values `get(0), get(1), ...`, whose stable sort has zeros at both middle places
+template <class Get> double median_zero_sign(size_t n2, Get get) {
+  const size_t mid = n2 / 2;
+  size_t below = 0; // entries that sort before every zero
+  for (size_t j = 0; j < n2; j++) below += get(j) < 0.0 ? 1 : 0;
+  const size_t want0 = mid - 1 - below, want1 = mid - below; // ranks of the two middle entries among the zeros, pushed order
+  size_t z = 0;
+  bool neg0 = false, neg1 = false;
+  for (size_t j = 0; j < n2 && z <= want1; j++) {
+    const double v = get(j);
+    if (v == 0.0) {
+      if (z == want0) neg0 = std::signbit(v);
+      if (z == want1) neg1 = std::signbit(v);
+      z++;
+    }
+  }
+  return neg0 && neg1 ? -0.0 : 0.0;
 }
 
 struct Builder {
@@ -118,7 +142,10 @@ struct Builder {
         hi[k] = std::fmax(hi[k], b.hi[k]);
       }
     }
-    double m[3] = {median_of(xs), median_of(ys), median_of(zs)}; // kdtree.rs:252-255
+    bool bz[3];
+    double m[3] = {median_of(xs, bz[0]), median_of(ys, bz[1]), median_of(zs, bz[2])}; // kdtree.rs:252-255
+    for (int k = 0; k < 3; k++)
+      if (bz[k]) m[k] = median_zero_sign(2 * n, [&](size_t j) { const Box& b = boxes[idx[j >> 1]]; return (j & 1) ? b.hi[k] : b.lo[k]; });
     size_t s[3];
     for (int dim = 0; dim < 3; dim++) { // partition_score kdtree.rs:257-268
       size_t l = 0, r = 0;

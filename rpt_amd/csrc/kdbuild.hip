@@ -82,8 +82,12 @@ __device__ __forceinline__ double ev_value(const Boxes& b, int k, uint32_t prim,
 __global__ void k_make_events(Boxes b, int k, uint32_t n, double* __restrict__ keys, uint32_t* __restrict__ vals) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys[2 * i] = b.lo[k][i]; vals[2 * i] = i << 1;
-  keys[2 * i + 1] = b.hi[k][i]; vals[2 * i + 1] = (i << 1) | 1u;
+  // (the KEY of a zero is +0.0 whatever its sign: the reference's comparison holds -0.0 == +0.0 and its sort is
+  // stable, kdtree.rs:251-254, so zeros of both signs stay in pushed order — the radix sort would put every -0.0
+  // first; the medians are read from the boxes, signs intact)
+  const double lo = b.lo[k][i], hi = b.hi[k][i];
+  keys[2 * i] = lo == 0.0 ? 0.0 : lo; vals[2 * i] = i << 1;
+  keys[2 * i + 1] = hi == 0.0 ? 0.0 : hi; vals[2 * i + 1] = (i << 1) | 1u;
 }
 __global__ void k_iota(uint32_t n, uint32_t* __restrict__ inst, uint32_t* __restrict__ task_of) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

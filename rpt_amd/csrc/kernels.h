@@ -53,7 +53,24 @@ struct SortBufs {
 #ifndef RPT_TT_LEVELS
 #define RPT_TT_LEVELS 7
 #endif
-// spill area of the traversal stack beyond the LDS levels: [KD_MAX_STACK - RPT_TT_LEVELS][threads] per array, one
+// rpt_tree_trace keeps the axis-indexed operands of its node step in LDS (AxisTab, kernels/wavefront.inc: 18.4 KB per
+// block) and fewer stack levels next to them; the spill area is sized for the kernel with the fewest LDS levels
+#ifndef RPT_TT_AXIS_LDS
+#define RPT_TT_AXIS_LDS 0
+#endif
+// rpt_tree_trace's LDS levels hold the TOP of the traversal stack (a window that slides; kernels/wavefront.inc)
+#ifndef RPT_TT_TOPWIN
+#define RPT_TT_TOPWIN 0
+#endif
+#ifndef RPT_TT_LEVELS_AX
+#define RPT_TT_LEVELS_AX 4
+#endif
+#if RPT_TT_AXIS_LDS && RPT_TT_LEVELS_AX < RPT_TT_LEVELS
+#define RPT_TT_LEVELS_MIN RPT_TT_LEVELS_AX
+#else
+#define RPT_TT_LEVELS_MIN RPT_TT_LEVELS
+#endif
+// spill area of the traversal stack beyond the LDS levels: [KD_MAX_STACK - RPT_TT_LEVELS_MIN][threads] per array, one
 // column per thread of the traversal grid (api.cpp allocates it for scenes with deep trees)
 // rpt_tree_generic's pending work (kernels/wavefront.inc), one column per thread of ITS grid: deferred far children
 // (six face parameters, t_split, node) and the suspended leaves of the groups above the tree being walked
@@ -87,6 +104,14 @@ struct QueryHook {
   void* ctx;
 };
 
+// launch_query's state and tuning, owned by the caller (one per handle): which of the two sets of tree counters the
+// next (tree, query) pair uses — both sets cleared when the buffer is made and after a failed render — and the
+// smallest query that is still sorted (RptSceneOptions::sort_min_rays)
+struct QueryTuning {
+  uint32_t ctr_set;
+  uint32_t sort_min_rays;
+};
+
 struct KernelTable {
   void (*raygen)(hipStream_t, const rptdev::Frame&, const rptdev::Camera&, const rptdev::PathState&, uint32_t n_paths);
   void (*extend)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n);
@@ -94,7 +119,8 @@ struct KernelTable {
                       double* out_n, int32_t* out_obj);
   // counters: [0] paths of the next depth, [1] hits, [2 + l] shadow rays queued for light l; sq: those queues ([light][cap])
   void (*shade)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::PathState&,
-                const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters, uint32_t* sq);
+                const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters, uint32_t* sq,
+                uint32_t* zero_next /* rpt_shade clears these zero_n words: the next depth's counters */, uint32_t zero_n);
   // visibility of one light over its shadow-ray queue, whole scene in the kernel (scenes without deep trees)
   void (*shadow_rays)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* sq,
                       const uint32_t* sq_count, uint32_t n, int light, double* srt);
@@ -116,7 +142,7 @@ struct KernelTable {
   void (*query)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                 int light, double* srt, const uint32_t* n_dev /* light >= 0: the device-side length of `queue` */, const uint8_t* obj_deep, const uint8_t* obj_tris, int num_objects,
                 uint32_t* tq, uint32_t* tq_ctr, uint32_t trace_blocks, const SortBufs* sort, const QueryHook* hook,
-                const StackSpill* spill /* the traversal stack beyond the LDS levels */);
+                const StackSpill* spill /* the traversal stack beyond the LDS levels */, QueryTuning* qt);
   size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
                      uint32_t depth, const double* srt);

@@ -161,8 +161,11 @@ def seven_nest():
     return scene, camera
 
 
-def axis_sun():
-    """Directional lights along the axes and in a coordinate plane over an UNTRANSFORMED deep mesh, a group of spheres and
+def axis_sun(oblique=False):
+    """(oblique: the same geometry under lights off every axis and coordinate plane — rays with a zero direction
+    component are then RARE for the library, which hands them to rpt_tree_generic instead of launching the ZEROS form of
+    rpt_tree_trace: launch_query, StackSpill::zeros_common.)
+    Directional lights along the axes and in a coordinate plane over an UNTRANSFORMED deep mesh, a group of spheres and
     a plane: every shadow ray has one or two direction components that are exactly zero (the compact traversal's and the
     leaf-box filter's special case, kernels/traversal.inc, shapes.inc)."""
     scene = Scene()
@@ -174,9 +177,13 @@ def axis_sun():
     scene.add(Object(KdTree(kids)).material(Material.diffuse(hex_color(0xCC7755))))
     scene.add(Object(plane((0.0, 1.0, 0.0), -1.2)).material(Material.diffuse(hex_color(0xAAAAAA))))
     scene.add(Light.Ambient((0.02, 0.02, 0.02)))
-    scene.add(Light.Directional((0.9, 0.9, 0.8), (0.0, -1.0, 0.0)))
-    scene.add(Light.Directional((0.3, 0.3, 0.5), (-1.0, -1.0, 0.0)))  # (exactly horizontal light would be 0/0 in bsdf on the plane)
-    scene.add(Light.Directional((0.4, 0.3, 0.3), (0.0, -0.6, -0.8)))
+    if oblique:
+        scene.add(Light.Directional((0.9, 0.9, 0.8), (0.1, -1.0, 0.2)))
+        scene.add(Light.Directional((0.3, 0.3, 0.5), (-1.0, -1.0, 0.3)))
+    else:
+        scene.add(Light.Directional((0.9, 0.9, 0.8), (0.0, -1.0, 0.0)))
+        scene.add(Light.Directional((0.3, 0.3, 0.5), (-1.0, -1.0, 0.0)))  # (exactly horizontal light would be 0/0 in bsdf on the plane)
+        scene.add(Light.Directional((0.4, 0.3, 0.3), (0.0, -0.6, -0.8)))
     camera = Camera.look_at((1.5, 2.5, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.7)
     return scene, camera
 
@@ -279,3 +286,47 @@ HI_NAMES = ["cornell_hi", "coverage_hi"]
 NAMES = ["sphere", "cornell", "dragon", "fractal_spheres", "glass", "wine_glass", "coverage",
          "monomial", "monomial_glass", "basic", "spheres", "compound", "fractal_teapots", "nested_groups",
          "teapot", "cylinder", "rustacean", "pegasus", "metal", "simple_video", "axis_sun", "deep_nest", "seven_nest"]
+
+
+# ---- kd-trees whose median is a zero of either sign (tests/test_kdtree.py, tests/test_gpu_kdbuild.py)
+def mixed_zero_boxes(order):
+    """100 boxes whose sorted x edges have twenty zeros around the middle: forty boxes left of x = 0, forty right of it,
+    ten that END at -0.0 ('A') and ten that START at +0.0 ('B'), the twenty in the index order given.  The root splits on
+    x (the largest extent; 60 of 100 boxes on either side) at a median that is (zero + zero) / 2 — its SIGN is decided by
+    which two zeros the stable sort leaves in the middle: the tenth and the eleventh of the twenty, in index order."""
+    rs = np.random.RandomState(11)
+    boxes = []
+    for i in range(40):
+        boxes.append([-2.0 + 0.01 * i, 0.0, 0.0, -1.0 + 0.01 * i, 0.3, 0.3])
+    touching = []
+    for kind in order:
+        touching.append([-1.0, 0.0, 0.0, -0.0, 0.3, 0.3] if kind == "A" else [0.0, 0.0, 0.0, 1.0, 0.3, 0.3])
+    boxes += touching
+    for i in range(40):
+        boxes.append([1.0 + 0.01 * i, 0.0, 0.0, 2.0 + 0.01 * i, 0.3, 0.3])
+    b = np.array(boxes)
+    b[:, [1, 2]] = rs.rand(len(b), 2) * 0.2  # y, z: small, distinct
+    b[:, [4, 5]] = b[:, [1, 2]] + 0.05 + rs.rand(len(b), 2) * 0.1
+    return b
+
+
+MIXED_ZERO_ORDERS = [
+    ("B" * 8 + "A" * 10 + "B" * 2, True),    # the 10th and 11th zero are both -0.0: (-0 + -0) / 2 = -0
+    ("A" * 10 + "B" * 10, False),            # -0.0, +0.0 in the middle: +0 (what a sort that puts every -0.0 first always gives)
+    ("A" * 8 + "B" * 4 + "A" * 2 + "B" * 6, False),  # +0.0, +0.0: +0 — where a -0.0-first order has -0.0, -0.0
+    ("AB" * 10, False),
+    ("B" + "A" * 10 + "B" * 9, True),
+]
+
+
+def mixed_zero_mesh(order):
+    """A mesh of one triangle per box of mixed_zero_boxes(order), each spanning its box exactly — the vertices' x are the
+    box's two x edges, signed zeros included — with flat normals: the kd-tree's root splits on x at a zero median."""
+    b = mixed_zero_boxes(order)
+    lo, hi = b[:, :3], b[:, 3:]
+    v0 = lo.copy()
+    v1 = np.stack([hi[:, 0], hi[:, 1], lo[:, 2]], axis=1)
+    v2 = np.stack([lo[:, 0], hi[:, 1], hi[:, 2]], axis=1)
+    n = np.cross(v1 - v0, v2 - v0)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    return np.concatenate([v0, v1, v2, n, n, n], axis=1)

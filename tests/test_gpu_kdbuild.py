@@ -10,6 +10,7 @@ import pytest
 import rpt_amd
 from rpt_amd import GpuScene, _abi, make_params, scenes
 from rpt_amd.device import kdtree_build
+from small_scenes import MIXED_ZERO_ORDERS, mixed_zero_boxes
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +26,7 @@ def assert_same_tree(a, b):
         assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
         same = a[k] == b[k]
         assert same.all(), (k, np.flatnonzero(~same)[:8], a[k][~same][:4], b[k][~same][:4])
+    assert (a["split"].view(np.uint64) == b["split"].view(np.uint64)).all()  # bitwise: the sign of a zero split too
 
 
 @pytest.mark.parametrize("n,seed", [(16, 3), (17, 4), (200, 5), (5000, 6), (40000, 7)])
@@ -51,6 +53,17 @@ def test_ties_flat_boxes_and_identical_boxes():
     b = np.concatenate([lo, lo + 0.01], axis=1)
     b[::7, 3:] += 5.0
     assert_same_tree(kdtree_build(b, device=0), kdtree_build(b))
+
+
+@pytest.mark.parametrize("order,negative", MIXED_ZERO_ORDERS)
+def test_zero_median_keeps_the_reference_order_among_equal_keys(order, negative):
+    """kdtree.rs:251-255 sorts STABLY under a comparison that holds -0.0 == +0.0; the device builder's radix sort would
+    put every -0.0 first, so its keys carry zeros without their sign (kdbuild.hip, k_make_events).  Same tree as the host
+    builder, the sign of the zero split included — and the sign is the reference's (tests/test_kdtree.py)."""
+    boxes = mixed_zero_boxes(order)
+    d, h = kdtree_build(boxes, device=0), kdtree_build(boxes)
+    assert_same_tree(d, h)
+    assert d["info"][0] == 0 and d["split"][0] == 0.0 and np.signbit(d["split"][0]) == negative
 
 
 def test_inputs_the_device_builder_does_not_take():

@@ -170,7 +170,7 @@ def test_high_sample_render_bit_equal_to_golden(name, pipeline):
     assert (img == ref).all(), "max |delta| = %g on %d pixels" % (np.abs(img - ref).max(), (img != ref).any(axis=1).sum())
 
 
-@pytest.mark.parametrize("route", ["per_tree", "per_tree_unsorted", "in_kernel", "default"])
+@pytest.mark.parametrize("route", ["per_tree", "per_tree_unsorted", "in_kernel", "default", "per_tree_zeros_rare", "per_tree_unsorted_zeros_rare"])
 def test_axis_parallel_rays_and_origins_on_split_planes(oracle, route, monkeypatch):
     """Rays with one or two direction components exactly zero — and, among them, origins that lie exactly ON a split
     plane (or a face of the bounds) of an axis the ray does not move along, where the reference's (value - o) / d is
@@ -180,10 +180,13 @@ def test_axis_parallel_rays_and_origins_on_split_planes(oracle, route, monkeypat
     from rpt_amd.device import kdtree_build
     if route.startswith("per_tree"):
         monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "1")
-        monkeypatch.setenv("RPTGPU_SORT_RAYS", "0" if route.endswith("unsorted") else "1")
+        monkeypatch.setenv("RPTGPU_SORT_RAYS", "0" if "unsorted" in route else "1")
+        monkeypatch.setenv("RPTGPU_SORT_MIN_RAYS", "0")
     if route == "in_kernel":
         monkeypatch.setenv("RPTGPU_RAYS_IN_KERNEL", "1")
-    scene, cam = small_scenes.axis_sun()
+    # *_zeros_rare: no light makes zero components common, so the per-tree pipeline has no ZEROS launch and every such
+    # ray of a tree goes through rpt_tree_generic (round 5)
+    scene, cam = small_scenes.axis_sun(oblique=route.endswith("zeros_rare"))
     rows = np.asarray(scene.objects[0].shape.triangles)
     v = rows[:, :9].reshape(-1, 3, 3)
     boxes = np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1)
@@ -215,6 +218,41 @@ def test_axis_parallel_rays_and_origins_on_split_planes(oracle, route, monkeypat
     t1, n1, ob1 = g.closest_hit(o, d)
     g.close()
     assert (ob0 == 0).sum() > 5000 and (ob0 == 1).sum() > 50
+    same_t = (t0.view(np.int64) == t1.view(np.int64)) | (np.isnan(t0) & np.isnan(t1))
+    assert same_t.all(), (route, int((~same_t).sum()), np.flatnonzero(~same_t)[:5])
+    assert (ob0 == ob1).all() and (n0.view(np.int64) == n1.view(np.int64)).all()
+
+
+@pytest.mark.parametrize("route", ["default", "per_tree"])
+@pytest.mark.parametrize("order,negative", small_scenes.MIXED_ZERO_ORDERS)
+def test_rays_from_a_zero_split_plane_of_either_sign(oracle, order, negative, route, monkeypatch):
+    """A mesh whose root split is a zero median of mixed-sign zeros (kdtree.rs:251-255: the stable sort's order among
+    equal keys decides its sign; tests/test_kdtree.py) and rays that start ON that plane, from +0.0 and from -0.0, a
+    third of them without motion along x: value - origin is a zero of either sign there, t_split a signed zero or 0/0.
+    Hit records bit-equal to the oracle's, whose tree has the same signed split."""
+    from rpt_amd.device import kdtree_build
+    if route == "per_tree":
+        monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "1")
+        monkeypatch.setenv("RPTGPU_SORT_MIN_RAYS", "0")
+    rows = small_scenes.mixed_zero_mesh(order)
+    v = rows[:, :9].reshape(-1, 3, 3)
+    tree = kdtree_build(np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1))
+    assert tree["info"][0] == 0 and tree["split"][0] == 0.0 and np.signbit(tree["split"][0]) == negative
+    scene = small_scenes.Scene()
+    scene.add(small_scenes.Object(small_scenes.Mesh(rows)).material(small_scenes.Material.diffuse(small_scenes.hex_color(0x808080))))
+    rs = np.random.RandomState(5)
+    n = 30000
+    o = np.stack([np.where(rs.rand(n) < 0.5, 0.0, -0.0), rs.rand(n) * 0.5 - 0.1, rs.rand(n) * 0.5 - 0.1], axis=1)
+    d = rs.randn(n, 3)
+    d[::3, 0] = 0.0
+    d[1::7, 0] = -0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o[::5, 0] = rs.randn(len(o[::5])) * 0.5  # and some from either side
+    g = GpuScene(scene, 0)
+    t0, n0, ob0 = oracle.OracleScene(scene).closest_hit(o, d)
+    t1, n1, ob1 = g.closest_hit(o, d)
+    g.close()
+    assert (ob0 == 0).sum() > 1000
     same_t = (t0.view(np.int64) == t1.view(np.int64)) | (np.isnan(t0) & np.isnan(t1))
     assert same_t.all(), (route, int((~same_t).sum()), np.flatnonzero(~same_t)[:5])
     assert (ob0 == ob1).all() and (n0.view(np.int64) == n1.view(np.int64)).all()

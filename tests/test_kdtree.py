@@ -6,6 +6,7 @@ import pytest
 
 from rpt_amd import _abi, scenes
 from rpt_amd.device import kdtree_build
+from small_scenes import MIXED_ZERO_ORDERS, mixed_zero_boxes
 
 
 def tri_boxes(rows):
@@ -24,6 +25,31 @@ def assert_same_tree(a, b):
     for k in ("split", "info", "a", "b", "refs"):
         assert a[k].shape == b[k].shape, k
         assert (a[k] == b[k]).all(), k
+    # splits BITWISE: -0.0 == +0.0 compares equal, and the sign of a zero split is what the order among equal keys decides
+    assert (a["split"].view(np.uint64) == b["split"].view(np.uint64)).all()
+
+
+def reference_median(pushed):
+    """kdtree.rs:251-255 + median() :347-355 on the values in the order construct pushes them (per index: p_min, p_max).
+    Python's sort, like Rust's sort_by, is stable and holds -0.0 == 0.0: equal entries keep their pushed order."""
+    s = sorted(pushed)
+    mid = len(s) // 2
+    return s[mid] if len(s) % 2 else (s[mid] + s[mid - 1]) / 2.0
+
+
+@pytest.mark.parametrize("order,negative", MIXED_ZERO_ORDERS)
+def test_zero_median_keeps_the_reference_order_among_equal_keys(oracle, order, negative):
+    """kdtree.rs:251-255: a STABLE sort under partial_cmp.  Zeros of both signs at the middle of a node's box edges: the
+    sign of the split is that of the reference's sort order — in the product's builder (order statistics, no sort), in
+    the oracle's (stable_sort) and in a direct transcription of median() over Python's stable sort."""
+    boxes = mixed_zero_boxes(order)
+    pushed = [v for b in boxes for v in (b[0], b[3])]
+    want = reference_median(pushed)
+    assert want == 0.0 and (np.signbit(want) == negative)
+    a, b = both(boxes, oracle)
+    assert_same_tree(a, b)
+    assert a["info"][0] == 0 and a["split"][0] == 0.0  # the root splits on x, at a zero
+    assert np.signbit(a["split"][0]) == negative and np.signbit(b["split"][0]) == negative
 
 
 @pytest.mark.parametrize("n,seed", [(0, 0), (1, 1), (15, 2), (16, 3), (17, 4), (200, 5), (5000, 6)])
