@@ -22,13 +22,6 @@ constexpr int KD_LDS_LEVELS = 12;   // stack levels the persistent kernel keeps 
 #ifndef RPT_KD_LDS_LEVELS_WF
 #define RPT_KD_LDS_LEVELS_WF 10
 #endif
-#ifndef RPT_KD_AXIS_LDS
-#define RPT_KD_AXIS_LDS 0
-#endif
-#ifndef RPT_KD_LDS_LEVELS_WF_AX
-#define RPT_KD_LDS_LEVELS_WF_AX 6
-#endif
-constexpr int KD_LDS_LEVELS_WF_AX = RPT_KD_LDS_LEVELS_WF_AX; // with the node step's axis table next to them (18.4 KB): 6 * 5 KB + 18.4 KB per block
 constexpr int KD_LDS_LEVELS_WF = RPT_KD_LDS_LEVELS_WF; // same for the wavefront kernels (3 blocks of 256 threads per CU share 160 KB)
 
 // One kd node: 16 B, one dwordx4 load.  Inner: a = left child (right = a+1), ib = axis (0..2).

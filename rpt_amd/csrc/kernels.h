@@ -53,23 +53,7 @@ struct SortBufs {
 #ifndef RPT_TT_LEVELS
 #define RPT_TT_LEVELS 7
 #endif
-// rpt_tree_trace keeps the axis-indexed operands of its node step in LDS (AxisTab, kernels/wavefront.inc: 18.4 KB per
-// block) and fewer stack levels next to them; the spill area is sized for the kernel with the fewest LDS levels
-#ifndef RPT_TT_AXIS_LDS
-#define RPT_TT_AXIS_LDS 0
-#endif
-// rpt_tree_trace's LDS levels hold the TOP of the traversal stack (a window that slides; kernels/wavefront.inc)
-#ifndef RPT_TT_TOPWIN
-#define RPT_TT_TOPWIN 0
-#endif
-#ifndef RPT_TT_LEVELS_AX
-#define RPT_TT_LEVELS_AX 4
-#endif
-#if RPT_TT_AXIS_LDS && RPT_TT_LEVELS_AX < RPT_TT_LEVELS
-#define RPT_TT_LEVELS_MIN RPT_TT_LEVELS_AX
-#else
 #define RPT_TT_LEVELS_MIN RPT_TT_LEVELS
-#endif
 // spill area of the traversal stack beyond the LDS levels: [KD_MAX_STACK - RPT_TT_LEVELS_MIN][threads] per array, one
 // column per thread of the traversal grid (api.cpp allocates it for scenes with deep trees)
 // rpt_tree_generic's pending work (kernels/wavefront.inc), one column per thread of ITS grid: deferred far children
