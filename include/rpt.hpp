@@ -641,6 +641,8 @@ class Renderer {
   Renderer& num_samples(uint32_t n) { num_samples_ = n; return *this; }
   Renderer& seed(uint64_t s) { seed_ = s; return *this; }   // addition: the reference seeds from entropy
   Renderer& device(int d) { device_ = d; return *this; }
+  // addition: the back-end's knobs (RptSceneOptions, include/rpt_gpu.h; start from rptgpu_scene_options_default)
+  Renderer& gpu_options(const RptSceneOptions& o) { options_ = o; have_options_ = true; return *this; }
 
   RgbImage render() { // renderer.rs:96-100
     Buffer buffer(width_, height_, filter_);
@@ -706,7 +708,7 @@ class Renderer {
       s.environment.width = e.hdri->width; s.environment.height = e.hdri->height;
       s.environment.texels = e.hdri->buf.data();
     }
-    check(rptgpu_scene_create(&s, device_, &handle_));
+    check(have_options_ ? rptgpu_scene_create_opts(&s, device_, &options_, &handle_) : rptgpu_scene_create(&s, device_, &handle_));
   }
   const Scene& scene_;
   Camera camera_;
@@ -715,6 +717,8 @@ class Renderer {
   Filter filter_;
   uint64_t seed_ = 0x52505447, samples_done_ = 0;
   int device_ = 0;
+  RptSceneOptions options_{};
+  bool have_options_ = false;
   rptgpu_scene* handle_ = nullptr;
 };
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPTGPU_ABI_VERSION 5
+#define RPTGPU_ABI_VERSION 6
 
 /* ---- error codes (replace the reference's panics: buffer.rs:26,33,89, plane.rs:35) ---- */
 enum {
@@ -204,7 +204,14 @@ typedef struct RptRenderParams {
   uint32_t part_count;
   uint32_t precision_mode; /* RPT_PRECISION_* */
   uint32_t flags;          /* RPT_FLAG_*      */
+  /* ABI v6 — how rptgpu_render_batch_reduce brings the ranks' pixels to the root (ignored by every other call):
+     RPT_COLLECTIVE_GATHER (also 0): each rank sends only the pixels it owns (ncclSend / ncclRecv), RPT_COLLECTIVE_REDUCE:
+     ncclReduce(sum) of full frames that are zero outside the rank's tiles.  Same frame either way.  Every rank of a
+     batch must pass the same value.  Until v5: the environment variable RPTGPU_COLLECTIVE, which still overrides. */
+  uint32_t collective;
+  uint32_t _reserved0;     /* 0 */
 } RptRenderParams;
+enum { RPT_COLLECTIVE_DEFAULT = 0, RPT_COLLECTIVE_GATHER = 1, RPT_COLLECTIVE_REDUCE = 2 };
 
 /* Per-kernel accounting since the last rptgpu_reset_stats (filled when
  * RPT_FLAG_PROFILE_KERNELS is set; counts are always maintained). */
@@ -255,6 +262,48 @@ int rptgpu_device_count(int* out_count);
  * rejected here, not at render time. */
 int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out);
 void rptgpu_scene_destroy(rptgpu_scene* h);
+
+/* ---- the knobs of a scene handle as a struct (ABI v6; SURVEY 5: "kernel tunables via a params struct, not env vars").
+ * None of them changes a result — they route work between kernels that compute the same bits (tests: every route
+ * against the same fixtures) and bound memory.  rptgpu_scene_options_default() fills in the defaults;
+ * rptgpu_scene_create(scene, device, out) is rptgpu_scene_create_opts with them.  The environment variables named
+ * beside the fields — the only interface until v5 — remain as OVERRIDES for experiments: read once, inside
+ * rptgpu_scene_create[_opts], never afterwards (a handle's behaviour is fixed when it is made).  What is left in the
+ * environment only: diagnostics (RPTGPU_PRINT_CREATE / _LAUNCH / _PHASES), the A/B switches RPTGPU_FLAT_TRIS_GLOBAL and
+ * RPTGPU_NO_PLANE_TABLE, the tests' fault injection RPTGPU_FAIL_COMM, and the launcher's RPTGPU_LOCAL_RANKS /
+ * LOCAL_WORLD_SIZE (how many ranks share the host's cores). */
+typedef struct RptSceneOptions {
+  uint32_t struct_size;           /* sizeof(RptSceneOptions) of the caller's header: lets the struct grow            */
+  uint32_t _reserved0;            /* 0                                                                               */
+  /* routing */
+  uint32_t deep_depth;            /* RPTGPU_DEEP_DEPTH (8): a kd-tree at least this deep gets its own ray queue, sort
+                                     and persistent traversal kernel; shallower ones are walked inside the path kernels */
+  uint32_t fast_max_depth;        /* RPTGPU_FAST_MAX_DEPTH (32): deeper trees never use the in-kernel traversals        */
+  int32_t sort_rays;              /* RPTGPU_SORT_RAYS (-1): 0 never, 1 every deep tree, -1 by the tree's footprint      */
+  int32_t rays_in_kernel;         /* RPTGPU_RAYS_IN_KERNEL (0): rptgpu_closest_hit keeps to one kernel for any scene    */
+  uint64_t sort_min_bytes;        /* RPTGPU_SORT_MIN_BYTES (8 MiB): nodes + leaf records of a tree whose rays are sorted */
+  uint64_t sort_shadow_min_bytes; /* RPTGPU_SORT_SHADOW_MIN_BYTES (32 MiB): ... whose SHADOW rays are sorted too         */
+  uint32_t sort_min_rays;         /* RPTGPU_SORT_MIN_RAYS (2^20): queries of fewer rays are not sorted                   */
+  int32_t nest_trace;             /* RPTGPU_NEST_TRACE (1): kd-trees of kd-trees in rpt_nest_trace (else rpt_tree_generic) */
+  int32_t leaf_boxes;             /* RPTGPU_LEAF_BOXES (1): the conservative f32 box in front of every exact leaf test    */
+  int32_t object_filter_min;      /* RPTGPU_OBJECT_FILTER_MIN (5): flat scenes of at least this many objects filter them; 0 = never */
+  uint64_t device_build_min;      /* RPTGPU_DEVICE_BUILD_MIN (32768; 4096 when ranks share the host): kd-trees of at least
+                                     this many primitives are built on the device; 0 = never                              */
+  uint32_t build_threads;         /* RPTGPU_BUILD_THREADS (0 = the usable cores): host threads of the flattening / kd build */
+  uint32_t paths_chunk;           /* RPTGPU_PATHS_CHUNK (16): samples per work item of the persistent path kernel         */
+  /* memory */
+  uint64_t workspace_bytes;       /* RPTGPU_WS_BYTES (96 GiB): cap of the wavefront pipeline's path state                 */
+  uint64_t lbuf_bytes;            /* RPTGPU_LBUF_BYTES (32 GiB): cap of the per-sample radiance buffer of rpt_paths        */
+  uint64_t target_paths;          /* RPTGPU_TARGET_PATHS (0 = what the workspace cap holds, at most 128 Mi): paths per pass */
+  /* multi-GPU */
+  double comm_timeout_s;          /* RPTGPU_COMM_TIMEOUT_S (300): a batch's exchange is given up after this long           */
+} RptSceneOptions;
+void rptgpu_scene_options_default(RptSceneOptions* out);
+/* opts == NULL: the defaults.  opts->struct_size must be sizeof(RptSceneOptions) of this ABI version (or smaller, of an
+ * older one: missing fields take their defaults); RPTGPU_E_INVALID_ARGUMENT otherwise. */
+int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOptions* opts, rptgpu_scene** out);
+/* the options a handle runs with, environment overrides applied */
+int rptgpu_scene_get_options(const rptgpu_scene* h, RptSceneOptions* out);
 
 /* ---- the hot path: replaces the body of Renderer::sample (renderer.rs:117-129).
  * Writes out_rgb[(y*width+x)*3+c] = mean over `iterations` paths of pixel (x,y), times

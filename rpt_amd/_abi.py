@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPTGPU_LIB") or os.path.join(HERE, "lib", "librptgpu.so")  # RPTGPU_LIB: dev A/B builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 RPTGPU_OK = 0
 RPTGPU_E_INVALID_ARGUMENT = -1
@@ -95,7 +95,24 @@ class RptRenderParams(C.Structure):
                 ("sample_index_base", C.c_uint64), ("tile_width", C.c_uint32),
                 ("tile_height", C.c_uint32), ("part_index", C.c_uint32),
                 ("part_count", C.c_uint32), ("precision_mode", C.c_uint32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("collective", C.c_uint32), ("_reserved0", C.c_uint32)]
+
+
+RPT_COLLECTIVE_DEFAULT, RPT_COLLECTIVE_GATHER, RPT_COLLECTIVE_REDUCE = 0, 1, 2
+
+
+class RptSceneOptions(C.Structure):
+    """include/rpt_gpu.h RptSceneOptions (ABI v6): the knobs of a scene handle; rptgpu_scene_options_default fills it."""
+    _fields_ = [("struct_size", C.c_uint32), ("_reserved0", C.c_uint32),
+                ("deep_depth", C.c_uint32), ("fast_max_depth", C.c_uint32),
+                ("sort_rays", C.c_int32), ("rays_in_kernel", C.c_int32),
+                ("sort_min_bytes", C.c_uint64), ("sort_shadow_min_bytes", C.c_uint64),
+                ("sort_min_rays", C.c_uint32), ("nest_trace", C.c_int32),
+                ("leaf_boxes", C.c_int32), ("object_filter_min", C.c_int32),
+                ("device_build_min", C.c_uint64),
+                ("build_threads", C.c_uint32), ("paths_chunk", C.c_uint32),
+                ("workspace_bytes", C.c_uint64), ("lbuf_bytes", C.c_uint64), ("target_paths", C.c_uint64),
+                ("comm_timeout_s", f64)]
 
 
 class RptStats(C.Structure):
@@ -123,6 +140,9 @@ SYMBOLS = [
     ("rptgpu_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("rptgpu_scene_create", C.c_int, [C.POINTER(RptScene), C.c_int, C.POINTER(_VP)]),
     ("rptgpu_scene_destroy", None, [_VP]),
+    ("rptgpu_scene_options_default", None, [C.POINTER(RptSceneOptions)]),
+    ("rptgpu_scene_create_opts", C.c_int, [C.POINTER(RptScene), C.c_int, C.POINTER(RptSceneOptions), C.POINTER(_VP)]),
+    ("rptgpu_scene_get_options", C.c_int, [_VP, C.POINTER(RptSceneOptions)]),
     ("rptgpu_render_batch", C.c_int, [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), _PD]),
     ("rptgpu_render_batch_device", C.c_int,
      [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), _VP, C.c_int, _VP]),

@@ -194,7 +194,8 @@ struct rptgpu_scene {
   bool sort_rays = false;          // some deep tree is large enough for sorting to pay (obj_deep[i] == 2)
   int sort_mode = -1;              // RPTGPU_SORT_RAYS: 0 never, 1 every deep tree, default: by footprint
   uint64_t sort_min_bytes = 8ull << 20;  // RPTGPU_SORT_MIN_BYTES: nodes + leaf records of a tree whose rays are worth sorting
-  QueryTuning qtune{0u, 1u << 20};  // launch_query's counter-set toggle; RPTGPU_SORT_MIN_RAYS: queries of fewer rays are not sorted
+  RptSceneOptions opt{};           // the handle's knobs: defaults, the caller's RptSceneOptions, environment overrides — fixed at creation
+  QueryTuning qtune{0u, 1u << 20};  // launch_query's counter-set toggle; opt.sort_min_rays
   uint64_t sort_shadow_min_bytes = 32ull << 20; // RPTGPU_SORT_SHADOW_MIN_BYTES: ... whose SHADOW rays are, too
   DevBuf<uint32_t> sort_kin, sort_kout, sort_vin;
   DevBuf<uint8_t> sort_tmp;
@@ -763,9 +764,87 @@ int rptgpu_device_count(int* out_count) {
   return RPTGPU_OK;
 }
 
+void rptgpu_scene_options_default(RptSceneOptions* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof *o);
+  o->struct_size = (uint32_t)sizeof *o;
+  o->deep_depth = 8;              // a tree this deep pays for compaction + its own launches
+  o->fast_max_depth = (uint32_t)rptdev::KD_MAX_STACK;
+  o->sort_rays = -1;
+  o->rays_in_kernel = 0;
+  o->sort_min_bytes = 8ull << 20;
+  o->sort_shadow_min_bytes = 32ull << 20;
+  o->sort_min_rays = 1u << 20;
+  o->nest_trace = 1;
+  o->leaf_boxes = 1;
+  o->object_filter_min = 5;
+  o->device_build_min = 32768;
+  o->build_threads = 0;
+  o->paths_chunk = 16;
+  o->workspace_bytes = 96ull << 30;
+  o->lbuf_bytes = 32ull << 30;
+  o->target_paths = 0;
+  o->comm_timeout_s = 300.0;
+}
+
+namespace {
+// the environment's overrides of the options (the variables' names: include/rpt_gpu.h, RptSceneOptions), read HERE and
+// nowhere else: once per handle, while it is made
+void apply_env_overrides(RptSceneOptions& o) {
+  auto ll = [](const char* name, long long& v) { if (const char* e = std::getenv(name)) { v = std::atoll(e); return true; } return false; };
+  long long v;
+  // several ranks on one node share the host's cores (host_scene.cpp usable_cpus): the device build pays earlier
+  for (const char* name : {"RPTGPU_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
+    if (const char* e = std::getenv(name)) {
+      if (std::atoi(e) > 1 && o.device_build_min == 32768) o.device_build_min = 4096;
+      break;
+    }
+  if (ll("RPTGPU_DEVICE_BUILD_MIN", v)) o.device_build_min = (uint64_t)std::max(0ll, v);
+  if (ll("RPTGPU_BUILD_THREADS", v)) o.build_threads = (uint32_t)std::max(1ll, v);
+  if (ll("RPTGPU_FAST_MAX_DEPTH", v)) o.fast_max_depth = (uint32_t)std::max(0ll, v);
+  if (ll("RPTGPU_DEEP_DEPTH", v)) o.deep_depth = (uint32_t)std::max(1ll, v);
+  if (ll("RPTGPU_RAYS_IN_KERNEL", v)) o.rays_in_kernel = v != 0 ? 1 : 0;
+  if (ll("RPTGPU_SORT_RAYS", v)) o.sort_rays = v != 0 ? 1 : 0;
+  if (ll("RPTGPU_SORT_MIN_BYTES", v)) o.sort_min_bytes = (uint64_t)std::max(0ll, v);
+  if (ll("RPTGPU_SORT_SHADOW_MIN_BYTES", v)) o.sort_shadow_min_bytes = (uint64_t)std::max(0ll, v);
+  if (ll("RPTGPU_SORT_MIN_RAYS", v)) o.sort_min_rays = (uint32_t)std::max(0ll, std::min(v, 0xffffffffll));
+  if (ll("RPTGPU_NEST_TRACE", v)) o.nest_trace = v != 0 ? 1 : 0;
+  if (ll("RPTGPU_LEAF_BOXES", v)) o.leaf_boxes = v != 0 ? 1 : 0;
+  if (ll("RPTGPU_OBJECT_FILTER_MIN", v)) o.object_filter_min = (int32_t)v;
+  if (ll("RPTGPU_PATHS_CHUNK", v)) o.paths_chunk = (uint32_t)std::max(1ll, v);
+  if (ll("RPTGPU_LBUF_BYTES", v) && v >= 24) o.lbuf_bytes = (uint64_t)v;
+  if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= 1024) o.target_paths = u; }
+  if (const char* e = std::getenv("RPTGPU_WS_BYTES")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= (1ull << 20)) o.workspace_bytes = u; }
+  if (const char* e = std::getenv("RPTGPU_COMM_TIMEOUT_S")) { double d = std::atof(e); if (d > 0.0) o.comm_timeout_s = d; }
+}
+} // namespace
+
+int rptgpu_scene_get_options(const rptgpu_scene* h, RptSceneOptions* out) {
+  if (!h || !out) return RPTGPU_E_INVALID_ARGUMENT;
+  *out = h->opt;
+  return RPTGPU_OK;
+}
+
 int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
+  return rptgpu_scene_create_opts(scene, device, nullptr, out);
+}
+
+int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOptions* user_opts, rptgpu_scene** out) {
   if (!scene || !out) return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
+  RptSceneOptions opt;
+  rptgpu_scene_options_default(&opt);
+  if (user_opts) { // a caller built against an older (smaller) struct: the fields it does not know keep their defaults
+    if (user_opts->struct_size < 8u || user_opts->struct_size > sizeof opt)
+      return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "RptSceneOptions::struct_size does not belong to this ABI version (use rptgpu_scene_options_default)");
+    std::memcpy(&opt, user_opts, user_opts->struct_size);
+    opt.struct_size = (uint32_t)sizeof opt;
+    if (opt.sort_rays < -1 || opt.sort_rays > 1 || opt.deep_depth < 1u || opt.paths_chunk < 1u || opt.lbuf_bytes < 24u ||
+        opt.workspace_bytes < (1ull << 20) || !(opt.comm_timeout_s > 0.0) || (opt.target_paths && opt.target_paths < 1024u))
+      return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "RptSceneOptions: a field is out of range");
+  }
+  apply_env_overrides(opt);
+  opt.fast_max_depth = std::min(opt.fast_max_depth, (uint32_t)rptdev::KD_MAX_STACK);
   rpthost::FlatScene fs;
   std::string err;
   int rc;
@@ -784,14 +863,8 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
   rpthost::BuildOptions bopt;
   {
     int nd = 0;
-    bopt.device_build_min = 32768;
-    // several ranks on one node share the host's cores (host_scene.cpp usable_cpus): the device build pays earlier
-    for (const char* name : {"RPTGPU_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
-      if (const char* e = std::getenv(name)) {
-        if (std::atoi(e) > 1) bopt.device_build_min = 4096;
-        break;
-      }
-    if (const char* e = std::getenv("RPTGPU_DEVICE_BUILD_MIN")) bopt.device_build_min = (size_t)std::max(0ll, std::atoll(e));
+    bopt.device_build_min = (size_t)opt.device_build_min;
+    bopt.build_threads = (int)opt.build_threads;
     if (bopt.device_build_min && hipGetDeviceCount(&nd) == hipSuccess && device >= 0 && device < nd) bopt.device = device;
     else (void)hipGetLastError();
   }
@@ -822,16 +895,19 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     // RPTGPU_FAST_MAX_DEPTH (tests): treat trees deeper than this as too deep for the in-kernel traversals.  The build rule
     // itself keeps real trees far below 32: both children of a median split hold (n + straddlers) / 2 primitives, so a path
     // d levels long needs 16 / 0.85^d primitives with an unsplittable sibling at every level, or 16 * 2^d balanced ones.
-    uint32_t fast_max_depth = (uint32_t)rptdev::KD_MAX_STACK;
-    if (const char* e = std::getenv("RPTGPU_FAST_MAX_DEPTH")) fast_max_depth = (uint32_t)std::max(0, std::min(std::atoi(e), (int)rptdev::KD_MAX_STACK));
+    h->opt = opt;
+    const uint32_t fast_max_depth = opt.fast_max_depth;
     h->max_tree_depth = fs.max_tree_depth;
-    uint32_t deep_depth = 8; // a tree this deep pays for compaction + its own launches
-    if (const char* e = std::getenv("RPTGPU_DEEP_DEPTH")) deep_depth = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RPTGPU_RAYS_IN_KERNEL")) h->rays_in_kernel = std::atoi(e) != 0 ? 1 : 0;
-    if (const char* e = std::getenv("RPTGPU_SORT_RAYS")) h->sort_mode = std::atoi(e) != 0 ? 1 : 0;
-    if (const char* e = std::getenv("RPTGPU_SORT_MIN_BYTES")) h->sort_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
-    if (const char* e = std::getenv("RPTGPU_SORT_SHADOW_MIN_BYTES")) h->sort_shadow_min_bytes = (uint64_t)std::max(0ll, std::atoll(e));
-    if (const char* e = std::getenv("RPTGPU_SORT_MIN_RAYS")) h->qtune.sort_min_rays = (uint32_t)std::max(0ll, std::min(std::atoll(e), 0xffffffffll));
+    const uint32_t deep_depth = opt.deep_depth;
+    h->rays_in_kernel = opt.rays_in_kernel;
+    h->sort_mode = opt.sort_rays;
+    h->sort_min_bytes = opt.sort_min_bytes;
+    h->sort_shadow_min_bytes = opt.sort_shadow_min_bytes;
+    h->qtune.sort_min_rays = opt.sort_min_rays;
+    h->paths_chunk = opt.paths_chunk;
+    h->lbuf_max_bytes = opt.lbuf_bytes;
+    h->target_paths = opt.target_paths;
+    h->ws_budget_bytes = opt.workspace_bytes;
     for (int i = 0; i < fs.num_objects; i++) {
       const rptdev::Inst& in = fs.insts[i];
       bool tree = in.kind == RPT_SHAPE_MESH || in.kind == RPT_SHAPE_GROUP;
@@ -879,8 +955,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
             ok = ok && fs.trees[kid.tree].regular;
           }
         }
-        const char* e = std::getenv("RPTGPU_NEST_TRACE");
-        if (ok && (!e || std::atoi(e) != 0) && fs.tree_depth[in.tree] + inner_depth + 2 <= (uint32_t)rptdev::KD_MAX_STACK) trace_kind = 2;
+        if (ok && opt.nest_trace != 0 && fs.tree_depth[in.tree] + inner_depth + 2 <= (uint32_t)rptdev::KD_MAX_STACK) trace_kind = 2;
         else generic_only = true;
       }
       if (generic_only) {
@@ -984,8 +1059,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
       // (host_scene.cpp fill_object_boxes).  RPTGPU_OBJECT_FILTER_MIN: from how many objects (0 = never).  Measured:
       // 2 objects -5..-11 % (C1, glass spheres), 5 objects +8 % (basic.rs), 6 objects +4 % (spheres.rs), 29 objects +40 %
       {
-        int min_objects = 5;
-        if (const char* e = std::getenv("RPTGPU_OBJECT_FILTER_MIN")) min_objects = std::atoi(e);
+        const int min_objects = opt.object_filter_min;
         const uint64_t every = fs.num_objects >= 64 ? ~0ull : (1ull << fs.num_objects) - 1ull;
         if (!lay.plane_cnt && min_objects > 0 && fs.num_objects >= min_objects && fs.obj_filter_ok &&
             (fs.obj_always & every) != every) {
@@ -1041,21 +1115,7 @@ int rptgpu_scene_create(const RptScene* scene, int device, rptgpu_scene** out) {
     d.env_width = fs.env_width; d.env_height = fs.env_height; d.env_kind = fs.env_kind;
     d.num_objects = fs.num_objects; d.num_lights = (int32_t)fs.lights.size();
     d.num_shadow_lights = fs.num_shadow_lights;
-    d.use_leaf_boxes = 1;
-    if (const char* e = std::getenv("RPTGPU_LEAF_BOXES")) d.use_leaf_boxes = std::atoi(e) != 0 ? 1 : 0;
-    if (const char* e = std::getenv("RPTGPU_LBUF_BYTES")) {
-      long long v = std::atoll(e);
-      if (v >= 24) h->lbuf_max_bytes = (uint64_t)v;
-    }
-    if (const char* e = std::getenv("RPTGPU_PATHS_CHUNK")) h->paths_chunk = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) {
-      uint64_t v = std::strtoull(e, nullptr, 10);
-      if (v >= 1024) h->target_paths = v;
-    }
-    if (const char* e = std::getenv("RPTGPU_WS_BYTES")) {
-      uint64_t v = std::strtoull(e, nullptr, 10);
-      if (v >= (1ull << 20)) h->ws_budget_bytes = v;
-    }
+    d.use_leaf_boxes = opt.leaf_boxes != 0 ? 1 : 0;
   } catch (const HipError& e) {
     int code = hip_fail(nullptr, e);
     delete h;
@@ -1136,13 +1196,6 @@ void ensure_gather_lists(rptgpu_scene* h, uint32_t width, uint32_t height, uint3
   h->gather32.alloc(std::max<uint64_t>(1, all.size() * 3));
   std::memcpy(h->gather_key, key, sizeof key);
 }
-double comm_timeout_s() {
-  if (const char* e = std::getenv("RPTGPU_COMM_TIMEOUT_S")) {
-    double v = std::atof(e);
-    if (v > 0.0) return v;
-  }
-  return 300.0;
-}
 } // namespace
 
 int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, int root,
@@ -1179,7 +1232,7 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
   // state instead of blocking, so that a peer's failure ends this call too
   auto wait_stream = [&]() -> int {
     if (world <= 1) { HIP_TRY(hipStreamSynchronize(h->stream)); return RPTGPU_OK; }
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(comm_timeout_s());
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(h->opt.comm_timeout_s);
     for (uint32_t spins = 0;; spins++) {
       hipError_t q = hipStreamQuery(h->stream);
       if (q == hipSuccess) return RPTGPU_OK;
@@ -1198,8 +1251,12 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
       if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
   };
-  const char* mode_env = std::getenv("RPTGPU_COLLECTIVE");
-  bool gather = !(mode_env && std::strcmp(mode_env, "reduce") == 0);
+  if (params->collective > RPT_COLLECTIVE_REDUCE) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "RptRenderParams::collective");
+  bool gather = params->collective != RPT_COLLECTIVE_REDUCE;
+  if (const char* mode_env = std::getenv("RPTGPU_COLLECTIVE")) { // (an override for experiments: every rank sees the same environment)
+    if (std::strcmp(mode_env, "reduce") == 0) gather = false;
+    else if (std::strcmp(mode_env, "gather") == 0) gather = true;
+  }
   if (world > 1 && gather && !(rc_lib->Send && rc_lib->Recv && rc_lib->GroupStart && rc_lib->GroupEnd)) gather = false;
   if (!h->comm) gather = false; // no communicator: a plain render straight into the frame (a 1-rank communicator still packs and places)
   try {

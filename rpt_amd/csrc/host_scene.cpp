@@ -53,9 +53,18 @@ int usable_cpus() {
 
 // fn(begin, end) over [0, n) in contiguous pieces on the usable CPUs; small ranges, or a box that cannot start threads,
 // run on the caller's.  For the per-triangle / per-leaf-entry loops of the flattening (independent items).
+// Host threads of the flattening and the kd build: RptSceneOptions::build_threads while a scene is being made
+// (flatten_scene sets it for its thread; the environment's override is already folded in, api.cpp), else — the
+// handle-less rptgpu_kdtree_build — RPTGPU_BUILD_THREADS; 0 = the usable cores.
+thread_local int t_build_threads = 0;
+int forced_build_threads() {
+  if (t_build_threads > 0) return t_build_threads;
+  if (const char* e = std::getenv("RPTGPU_BUILD_THREADS")) return std::max(1, std::atoi(e));
+  return 0;
+}
 template <class F> void parallel_for(size_t n, size_t min_per_thread, F fn) {
   int threads = (int)std::min<size_t>((size_t)std::min(usable_cpus(), 32), n / std::max<size_t>(min_per_thread, 1));
-  if (const char* e = std::getenv("RPTGPU_BUILD_THREADS")) threads = std::min(threads, std::max(1, std::atoi(e)));
+  if (const int f = forced_build_threads()) threads = std::min(threads, f);
   if (threads <= 1) { fn((size_t)0, n); return; }
   std::vector<std::thread> pool;
   const size_t step = (n + (size_t)threads - 1) / (size_t)threads;
@@ -306,7 +315,7 @@ void kd_build(const std::vector<Box>& boxes, KdBuild& out, int threads) {
   }
   if (threads <= 0) {
     threads = usable_cpus();
-    if (const char* e = std::getenv("RPTGPU_BUILD_THREADS")) threads = std::max(1, std::atoi(e));
+    if (const int f = forced_build_threads()) threads = f;
     threads = std::min(threads, 32);
   }
   build_subtree(boxes, idx, 0, root, out, threads);
@@ -503,6 +512,46 @@ struct Flattener {
   const BuildOptions* build = nullptr;
   bool light_shape = false; // the shape being flattened is a Light::Object's
 
+  // The DEVICE order of a tree's nodes.  The builders number them as the sequential depth-first build creates them: a
+  // node's children as a pair, then the left subtree, then the right.  Here the pairs of two SIBLING inner nodes are laid
+  // side by side — pair(c0) directly before pair(c1) — so that their parent can name either without reading the child:
+  // an inner node keeps, in the bits of `ib` above the axis, which of its children are inner (bits 2, 3) and the index g
+  // of the first of those pairs (bits 4..31: pair(c0) = g, pair(c1) = g + 2; with only c1 inner g = pair(c1) - 2).
+  // rpt_tree_trace requests a child's pair one step ahead with it (kernels/wavefront.inc, node_step); every other
+  // traversal reads `ib & 3` of an inner node and follows `a`, which any numbering satisfies.  Order: root, its pair, then
+  // depth-first over the inner nodes, each placing its two children's pairs.  Leaves keep (first entry, count): the
+  // leaf ORDER, and with it every array indexed by leaf entries, is untouched.
+  static void quad_order(std::vector<rptdev::KdNode>& nodes) {
+    if (nodes.empty() || (nodes[0].ib & 3u) == 3u) return;
+    std::vector<rptdev::KdNode> out;
+    out.reserve(nodes.size());
+    out.push_back(nodes[0]);
+    out.push_back(nodes[nodes[0].a]);
+    out.push_back(nodes[nodes[0].a + 1u]);
+    out[0].a = 1u;
+    std::vector<uint32_t> todo{0u}; // inner nodes (new indices) whose children are placed and still carry OLD `a`s
+    while (!todo.empty()) {
+      const uint32_t y = todo.back();
+      todo.pop_back();
+      const uint32_t c[2] = {out[y].a, out[y].a + 1u};
+      bool inner[2];
+      for (int k = 0; k < 2; k++) {
+        inner[k] = (out[c[k]].ib & 3u) != 3u;
+        if (inner[k]) {
+          const uint32_t old_a = out[c[k]].a, p = (uint32_t)out.size();
+          out.push_back(nodes[old_a]);
+          out.push_back(nodes[old_a + 1u]);
+          out[c[k]].a = p;
+        }
+      }
+      const uint32_t g = inner[0] ? out[c[0]].a : (inner[1] ? out[c[1]].a - 2u : 0u);
+      out[y].ib = (out[y].ib & 3u) | (inner[0] ? 4u : 0u) | (inner[1] ? 8u : 0u) | (g << 4);
+      if (inner[1]) todo.push_back(c[1]);
+      if (inner[0]) todo.push_back(c[0]); // (the left subtree first, as the builders number them)
+    }
+    nodes.swap(out);
+  }
+
   int add_tree(const std::vector<Box>& boxes, uint32_t prim_base) {
     KdBuild kb;
     bool on_device = false;
@@ -539,6 +588,7 @@ struct Flattener {
     for (const Box& b : boxes) bounds = merge(bounds, b);
     for (int k = 0; k < 3; k++) { t.bounds[k] = bounds.lo[k]; t.bounds[3 + k] = bounds.hi[k]; }
     // child / ref indices stay tree-relative; kernels add node_base / ref_base
+    quad_order(kb.nodes);
     fs.nodes.insert(fs.nodes.end(), kb.nodes.begin(), kb.nodes.end());
     fs.refs.insert(fs.refs.end(), kb.refs.begin(), kb.refs.end());
     fs.trees.push_back(t);
@@ -691,6 +741,11 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const Bui
     err = "null objects/lights";
     return RPTGPU_E_INVALID_ARGUMENT;
   }
+  struct ThreadsScope { // (restored on every way out)
+    int saved;
+    explicit ThreadsScope(int v) : saved(t_build_threads) { t_build_threads = v; }
+    ~ThreadsScope() { t_build_threads = saved; }
+  } threads_scope(build ? build->build_threads : 0);
   Flattener fl{fs, err, {}, build, {}};
   fs.num_objects = (int32_t)sc.num_objects;
   fs.insts.resize(sc.num_objects);

@@ -34,6 +34,7 @@ bool kd_build_device(const std::vector<Box>& boxes, KdBuild& out, int device, st
 struct BuildOptions {
   int device = -1;
   size_t device_build_min = 0;
+  int build_threads = 0; // RptSceneOptions::build_threads: 0 = the usable cores
 };
 
 struct FlatScene {

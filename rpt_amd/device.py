@@ -10,8 +10,9 @@ from . import _abi
 
 def make_params(width, height, max_bounces, iterations, exposure_value=0.0, seed=0x52505447,
                 sample_index_base=0, tile=(32, 8), part=(0, 1),
-                precision=_abi.RPT_PRECISION_F64_STRICT, flags=0):
+                precision=_abi.RPT_PRECISION_F64_STRICT, flags=0, collective=_abi.RPT_COLLECTIVE_DEFAULT):
     p = _abi.RptRenderParams()
+    p.collective = int(collective)
     p.width, p.height, p.max_bounces, p.iterations = int(width), int(height), int(max_bounces), int(iterations)
     p.exposure_value = float(exposure_value)
     p.seed, p.sample_index_base = int(seed), int(sample_index_base)
@@ -19,6 +20,18 @@ def make_params(width, height, max_bounces, iterations, exposure_value=0.0, seed
     p.part_index, p.part_count = int(part[0]), int(part[1])
     p.precision_mode, p.flags = int(precision), int(flags)
     return p
+
+
+def scene_options(**fields):
+    """RptSceneOptions with the library's defaults (rptgpu_scene_options_default) and the given fields set."""
+    o = _abi.RptSceneOptions()
+    _abi.load_library().rptgpu_scene_options_default(C.byref(o))
+    known = {name for name, _ in _abi.RptSceneOptions._fields_}
+    for k, v in fields.items():
+        if k not in known or k in ("struct_size", "_reserved0"):
+            raise TypeError("RptSceneOptions has no field %r" % k)
+        setattr(o, k, v)
+    return o
 
 
 def device_count():
@@ -31,13 +44,25 @@ def device_count():
 class GpuScene:
     """Owns one `rptgpu_scene*` (device-resident flattened scene + kd-trees)."""
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, **options):
+        """options: fields of RptSceneOptions (include/rpt_gpu.h) by name, e.g. GpuScene(scene, 0, sort_rays=0,
+        deep_depth=1); the rest keep their defaults.  RPTGPU_* environment variables still override."""
         self.lib = _abi.load_library()
         desc, keep = scene.lower()
         h = C.c_void_p()
-        _abi.check(self.lib.rptgpu_scene_create(C.byref(desc), int(device), C.byref(h)))
+        if options:
+            o = scene_options(**options)
+            _abi.check(self.lib.rptgpu_scene_create_opts(C.byref(desc), int(device), C.byref(o), C.byref(h)))
+        else:
+            _abi.check(self.lib.rptgpu_scene_create(C.byref(desc), int(device), C.byref(h)))
         self.handle = h
         self.device = int(device)
+
+    def options(self):
+        """The options the handle runs with (defaults, the caller's, environment overrides) as a dict."""
+        o = _abi.RptSceneOptions()
+        _abi.check(self.lib.rptgpu_scene_get_options(self.handle, C.byref(o)), self.handle)
+        return {name: getattr(o, name) for name, _ in _abi.RptSceneOptions._fields_ if not name.startswith("_")}
 
     def close(self):
         if getattr(self, "handle", None):

@@ -21,7 +21,7 @@ use std::sync::Arc;
 pub mod ffi {
     use std::os::raw::{c_char, c_int, c_void};
 
-    pub const RPTGPU_ABI_VERSION: c_int = 5;
+    pub const RPTGPU_ABI_VERSION: c_int = 6;
     pub const RPTGPU_OK: c_int = 0;
     pub const RPTGPU_E_INVALID_ARGUMENT: c_int = -1;
     pub const RPTGPU_E_UNSUPPORTED_SHAPE: c_int = -2;
@@ -175,6 +175,33 @@ pub mod ffi {
         pub part_count: u32,
         pub precision_mode: u32,
         pub flags: u32,
+        pub collective: u32,
+        pub _reserved0: u32,
+    }
+
+    /// The knobs of a scene handle (ABI v6): `rptgpu_scene_options_default` fills it, `rptgpu_scene_create_opts` takes it.
+    #[repr(C)]
+    #[derive(Copy, Clone, Debug)]
+    pub struct RptSceneOptions {
+        pub struct_size: u32,
+        pub _reserved0: u32,
+        pub deep_depth: u32,
+        pub fast_max_depth: u32,
+        pub sort_rays: i32,
+        pub rays_in_kernel: i32,
+        pub sort_min_bytes: u64,
+        pub sort_shadow_min_bytes: u64,
+        pub sort_min_rays: u32,
+        pub nest_trace: i32,
+        pub leaf_boxes: i32,
+        pub object_filter_min: i32,
+        pub device_build_min: u64,
+        pub build_threads: u32,
+        pub paths_chunk: u32,
+        pub workspace_bytes: u64,
+        pub lbuf_bytes: u64,
+        pub target_paths: u64,
+        pub comm_timeout_s: f64,
     }
 
     #[repr(C)]
@@ -224,6 +251,9 @@ pub mod ffi {
         pub fn rptgpu_device_count(out_count: *mut c_int) -> c_int;
         pub fn rptgpu_scene_create(scene: *const RptScene, device: c_int, out: *mut *mut rptgpu_scene) -> c_int;
         pub fn rptgpu_scene_destroy(h: *mut rptgpu_scene);
+        pub fn rptgpu_scene_options_default(out: *mut RptSceneOptions);
+        pub fn rptgpu_scene_create_opts(scene: *const RptScene, device: c_int, opts: *const RptSceneOptions, out: *mut *mut rptgpu_scene) -> c_int;
+        pub fn rptgpu_scene_get_options(h: *const rptgpu_scene, out: *mut RptSceneOptions) -> c_int;
         pub fn rptgpu_render_batch(h: *mut rptgpu_scene, camera: *const RptCamera, params: *const RptRenderParams, out_rgb: *mut f64) -> c_int;
         pub fn rptgpu_render_batch_device(h: *mut rptgpu_scene, camera: *const RptCamera, params: *const RptRenderParams, d_out: *mut c_void, out_is_f32: c_int, stream: *mut c_void) -> c_int;
         pub fn rptgpu_comm_unique_id(out_id: *mut u8) -> c_int;
@@ -248,7 +278,7 @@ pub mod ffi {
     }
 }
 
-pub use ffi::{RptCamera, RptMaterial, RptRenderParams, RptStats, RptTransform, RptTriangle};
+pub use ffi::{RptCamera, RptMaterial, RptRenderParams, RptSceneOptions, RptStats, RptTransform, RptTriangle};
 
 // ------------------------------------------------------------------------------------------------
 // Safe layer
@@ -561,7 +591,8 @@ mod layout_tests {
         assert_eq!(size_of::<RptEnvironment>(), 48);
         assert_eq!(size_of::<RptScene>(), 80);
         assert_eq!(size_of::<RptCamera>(), 96);
-        assert_eq!(size_of::<RptRenderParams>(), 64);
+        assert_eq!(size_of::<RptRenderParams>(), 72);
+        assert_eq!(size_of::<RptSceneOptions>(), 104);
         assert_eq!(size_of::<RptStats>(), 200);
         assert_eq!(size_of::<RptKdTree>(), 64);
     }

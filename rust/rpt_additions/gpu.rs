@@ -124,6 +124,8 @@ impl GpuBackend {
             part_count: 1,
             precision_mode: 0, // RPT_PRECISION_F64_STRICT: IEEE f64, no FMA contraction — rpt's own arithmetic
             flags: 0,
+            collective: 0, // RPT_COLLECTIVE_DEFAULT (only rptgpu_render_batch_reduce looks at it)
+            _reserved0: 0,
         };
         let mut flat = vec![0.0f64; r.width as usize * r.height as usize * 3];
         self.scene

@@ -27,13 +27,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == {s[0] for s in _abi.SYMBOLS}
-    assert lib.rptgpu_abi_version() == _abi.ABI_VERSION == 5
+    assert lib.rptgpu_abi_version() == _abi.ABI_VERSION == 6
 
 
 def test_struct_sizes_match_header(tmp_path):
     # compile the header with gcc (as C) and compare sizeof of every struct with the ctypes mirror
     names = ["RptMaterial", "RptTriangle", "RptTransform", "RptShape", "RptObject", "RptLight",
-             "RptEnvironment", "RptScene", "RptCamera", "RptRenderParams", "RptStats", "RptKdTree"]
+             "RptEnvironment", "RptScene", "RptCamera", "RptRenderParams", "RptSceneOptions", "RptStats", "RptKdTree"]
     src = '#include <stdio.h>\n#include "rpt_gpu.h"\nint main(void){' + "".join(
         'printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}"
     c = tmp_path / "sz.c"
@@ -44,6 +44,42 @@ def test_struct_sizes_match_header(tmp_path):
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     for n, sz in zip(names, sizes):
         assert C.sizeof(getattr(_abi, n)) == sz, n
+
+
+def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch):
+    """RptSceneOptions (ABI v6): the library fills the defaults, rejects a struct of a size it does not know and fields out
+    of range BEFORE anything else is looked at (no GPU needed), and takes a smaller struct of an older header."""
+    lib = _abi.load_library()
+    o = _abi.RptSceneOptions()
+    lib.rptgpu_scene_options_default(C.byref(o))
+    assert o.struct_size == C.sizeof(_abi.RptSceneOptions)
+    assert (o.deep_depth, o.fast_max_depth, o.sort_rays, o.rays_in_kernel) == (8, 32, -1, 0)
+    assert (o.sort_min_bytes, o.sort_shadow_min_bytes, o.sort_min_rays) == (8 << 20, 32 << 20, 1 << 20)
+    assert (o.nest_trace, o.leaf_boxes, o.object_filter_min, o.device_build_min) == (1, 1, 5, 32768)
+    assert (o.build_threads, o.paths_chunk, o.workspace_bytes, o.lbuf_bytes, o.target_paths) == (0, 16, 96 << 30, 32 << 30, 0)
+    assert o.comm_timeout_s == 300.0
+    scene = rpt_amd.Scene()
+    scene.add(rpt_amd.Object(rpt_amd.sphere()))
+    desc, keep = scene.lower()
+    h = C.c_void_p()
+
+    def create(opts):
+        return lib.rptgpu_scene_create_opts(C.byref(desc), 0, C.byref(opts) if opts is not None else None, C.byref(h))
+    assert create(None) == _abi.RPTGPU_E_NO_DEVICE  # valid options: the flattening runs, then the device is missing
+    assert create(o) == _abi.RPTGPU_E_NO_DEVICE
+    bad = rpt_amd.device.scene_options()
+    bad.struct_size = C.sizeof(_abi.RptSceneOptions) + 8
+    assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT and b"struct_size" in lib.rptgpu_last_error_detail(None)
+    for field, value in (("sort_rays", 2), ("deep_depth", 0), ("paths_chunk", 0), ("workspace_bytes", 1000),
+                         ("comm_timeout_s", 0.0), ("target_paths", 5)):
+        bad = rpt_amd.device.scene_options(**{field: value})
+        assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT, field
+    old = rpt_amd.device.scene_options(sort_rays=0)
+    old.struct_size = 24  # a caller that knows the first four fields only: the rest keep their defaults
+    assert create(old) == _abi.RPTGPU_E_NO_DEVICE
+    with pytest.raises(TypeError):
+        rpt_amd.device.scene_options(no_such_field=1)
+    assert lib.rptgpu_scene_get_options(None, C.byref(o)) == _abi.RPTGPU_E_INVALID_ARGUMENT
 
 
 def test_strerror_and_kernel_names():
