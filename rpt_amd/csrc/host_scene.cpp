@@ -512,46 +512,6 @@ struct Flattener {
   const BuildOptions* build = nullptr;
   bool light_shape = false; // the shape being flattened is a Light::Object's
 
-  // The DEVICE order of a tree's nodes.  The builders number them as the sequential depth-first build creates them: a
-  // node's children as a pair, then the left subtree, then the right.  Here the pairs of two SIBLING inner nodes are laid
-  // side by side — pair(c0) directly before pair(c1) — so that their parent can name either without reading the child:
-  // an inner node keeps, in the bits of `ib` above the axis, which of its children are inner (bits 2, 3) and the index g
-  // of the first of those pairs (bits 4..31: pair(c0) = g, pair(c1) = g + 2; with only c1 inner g = pair(c1) - 2).
-  // rpt_tree_trace requests a child's pair one step ahead with it (kernels/wavefront.inc, node_step); every other
-  // traversal reads `ib & 3` of an inner node and follows `a`, which any numbering satisfies.  Order: root, its pair, then
-  // depth-first over the inner nodes, each placing its two children's pairs.  Leaves keep (first entry, count): the
-  // leaf ORDER, and with it every array indexed by leaf entries, is untouched.
-  static void quad_order(std::vector<rptdev::KdNode>& nodes) {
-    if (nodes.empty() || (nodes[0].ib & 3u) == 3u) return;
-    std::vector<rptdev::KdNode> out;
-    out.reserve(nodes.size());
-    out.push_back(nodes[0]);
-    out.push_back(nodes[nodes[0].a]);
-    out.push_back(nodes[nodes[0].a + 1u]);
-    out[0].a = 1u;
-    std::vector<uint32_t> todo{0u}; // inner nodes (new indices) whose children are placed and still carry OLD `a`s
-    while (!todo.empty()) {
-      const uint32_t y = todo.back();
-      todo.pop_back();
-      const uint32_t c[2] = {out[y].a, out[y].a + 1u};
-      bool inner[2];
-      for (int k = 0; k < 2; k++) {
-        inner[k] = (out[c[k]].ib & 3u) != 3u;
-        if (inner[k]) {
-          const uint32_t old_a = out[c[k]].a, p = (uint32_t)out.size();
-          out.push_back(nodes[old_a]);
-          out.push_back(nodes[old_a + 1u]);
-          out[c[k]].a = p;
-        }
-      }
-      const uint32_t g = inner[0] ? out[c[0]].a : (inner[1] ? out[c[1]].a - 2u : 0u);
-      out[y].ib = (out[y].ib & 3u) | (inner[0] ? 4u : 0u) | (inner[1] ? 8u : 0u) | (g << 4);
-      if (inner[1]) todo.push_back(c[1]);
-      if (inner[0]) todo.push_back(c[0]); // (the left subtree first, as the builders number them)
-    }
-    nodes.swap(out);
-  }
-
   int add_tree(const std::vector<Box>& boxes, uint32_t prim_base) {
     KdBuild kb;
     bool on_device = false;
@@ -588,7 +548,6 @@ struct Flattener {
     for (const Box& b : boxes) bounds = merge(bounds, b);
     for (int k = 0; k < 3; k++) { t.bounds[k] = bounds.lo[k]; t.bounds[3 + k] = bounds.hi[k]; }
     // child / ref indices stay tree-relative; kernels add node_base / ref_base
-    quad_order(kb.nodes);
     fs.nodes.insert(fs.nodes.end(), kb.nodes.begin(), kb.nodes.end());
     fs.refs.insert(fs.refs.end(), kb.refs.begin(), kb.refs.end());
     fs.trees.push_back(t);
