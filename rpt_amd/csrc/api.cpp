@@ -458,6 +458,7 @@ void release_workspace(rptgpu_scene* h) {
   h->ray.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->nrec.release(); h->rec.release();
   h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
   h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release(); h->tree_rays.release();
+  h->gen_defer.release(); h->gen_frame.release(); h->gen_threads = 0; // rpt_tree_generic's columns (ensure_generic makes them again)
   h->ws_cap = 0; h->ws_bounces = 0;
 }
 
@@ -1227,6 +1228,25 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
     abort_comm();
     return fail(h, code, why);
   };
+  // After an abort the library's stream may still hold this batch's work — the scatter kernels and, on the root, the
+  // copy into the CALLER's out_rgb32 — which the aborted collective now releases.  It is drained before the call
+  // returns its error, so that nothing is written into the caller's buffer afterwards and the handle's next call finds
+  // an idle stream.  Bounded: if the device does not finish within the communicator's time-out again (it should within
+  // milliseconds once ncclCommAbort has returned), the handle gets a fresh stream, the old one is abandoned to the
+  // runtime, and the error says that out_rgb32 may still be written to until the device is done.
+  auto drain_after_abort = [&](std::string& note) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(h->opt.comm_timeout_s);
+    for (uint32_t spins = 0;; spins++) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q != hipErrorNotReady) { if (q != hipSuccess) (void)hipGetLastError(); return; } // idle (or broken: nothing left to wait for)
+      if (std::chrono::steady_clock::now() > deadline) break;
+      if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    hipStream_t fresh = nullptr;
+    if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) h->stream = fresh; // (the old stream is not destroyed: that would block on it)
+    else (void)hipGetLastError();
+    note = " — the library's stream did not drain after the abort: out_rgb32 may be written to until the device finishes";
+  };
   if (rank == root && !out_rgb32) return fail_comm(RPTGPU_E_INVALID_ARGUMENT, "null out_rgb32 on the root rank");
   // waits for the library's stream; with a communicator it polls the stream together with RCCL's asynchronous error
   // state instead of blocking, so that a peer's failure ends this call too
@@ -1242,12 +1262,19 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
         int grc = rc_lib->CommGetAsyncError(h->comm, &aerr);
         if (grc != 0 || (aerr != 0 && aerr != RCCL_IN_PROGRESS)) {
           const int code = grc != 0 ? grc : aerr;
-          return fail_comm(RPTGPU_E_COMM, std::string("asynchronous RCCL error while the batch's collective was in flight: ") +
-                                              (rc_lib->GetErrorString ? rc_lib->GetErrorString(code) : "error"));
+          abort_comm();
+          std::string note;
+          drain_after_abort(note);
+          return fail(h, RPTGPU_E_COMM, std::string("asynchronous RCCL error while the batch's collective was in flight: ") +
+                                            (rc_lib->GetErrorString ? rc_lib->GetErrorString(code) : "error") + note);
         }
       }
-      if (std::chrono::steady_clock::now() > deadline)
-        return fail_comm(RPTGPU_E_COMM, "the batch's collective did not finish within RPTGPU_COMM_TIMEOUT_S (a peer rank failed or hangs)");
+      if (std::chrono::steady_clock::now() > deadline) {
+        abort_comm();
+        std::string note;
+        drain_after_abort(note);
+        return fail(h, RPTGPU_E_COMM, "the batch's collective did not finish within RptSceneOptions::comm_timeout_s (a peer rank failed or hangs)" + note);
+      }
       if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
   };
@@ -1344,6 +1371,8 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
     h->stats.reduce_copy_ms += ms[2];
   } catch (const HipError& e) {
     abort_comm();
+    std::string note;
+    if (world > 1) drain_after_abort(note);
     return hip_fail(h, e);
   } catch (const std::bad_alloc&) {
     return fail_comm(RPTGPU_E_HIP, "out of host memory");
@@ -1364,6 +1393,8 @@ int rptgpu_render_batch_emulate_ranks(rptgpu_scene* h, const RptCamera* camera, 
     HIP_TRY(hipMemsetAsync(h->frame32_sum.p, 0xff, n * sizeof(float), h->stream)); // NaNs: a pixel nobody places shows
   } catch (const HipError& e) {
     return hip_fail(h, e);
+  } catch (const std::bad_alloc&) { // (ensure_gather_lists builds host lists of width * height entries)
+    return fail(h, RPTGPU_E_OUT_OF_MEMORY, "host allocation failed");
   }
   // what each rank would send, rendered here one after the other straight into the root's receive buffer
   for (int r = 0; r < world; r++) {
