@@ -390,7 +390,7 @@ int rptgpu_kdtree_build(const double* boxes, uint64_t n, RptKdTree* out);
 /* The same tree — node for node, entry for entry — built on HIP device `device` (events sorted once per axis, one
  * round of scans and stable scatters per tree level).  rptgpu_scene_create uses it by itself for trees of at least
  * RPTGPU_DEVICE_BUILD_MIN primitives (default 32768).  RPTGPU_E_INVALID_ARGUMENT for inputs it does not take (fewer
- * than 16 boxes, non-finite coordinates, a tree deeper than the device stack): build those with rptgpu_kdtree_build. */
+ * than 16 boxes, non-finite coordinates): build those with rptgpu_kdtree_build. */
 int rptgpu_kdtree_build_device(const double* boxes, uint64_t n, int device, RptKdTree* out);
 void rptgpu_kdtree_free(RptKdTree* tree);
 

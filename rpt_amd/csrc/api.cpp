@@ -378,6 +378,20 @@ void ensure_generic(rptgpu_scene* h, bool all) {
   h->spill.gen_blocks_all = h->gen_threads / 256u >= blocks_all ? blocks_all : blocks_few;
 }
 
+// rpt_tree_generic raises a flag when a traversal outgrows its columns (they are sized from the scene, so that is a bug,
+// not an input): read and cleared after every batch of queries — a render's and rptgpu_closest_hit's alike, so that the
+// flag of one call never surfaces in the next.  The stream must be idle.
+bool generic_overflowed(rptgpu_scene* h, hipStream_t st) {
+  uint32_t flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, h->gen_overflow.p, sizeof flag, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (flag) {
+    HIP_TRY(hipMemsetAsync(h->gen_overflow.p, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return flag != 0;
+}
+
 void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
   if (cap <= h->ws_cap && max_bounces <= h->ws_bounces && h->ray.p) return;
   cap = std::max(cap, h->ws_cap);
@@ -605,9 +619,13 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, target / npix));
       // several handles (or processes) on one GPU each see the same `free` figure: if the pass does not fit after
       // all, halve it instead of failing the render (a smaller pass is only slower)
+      // (rpt_tree_generic's large grid — whole objects, or under RPT_FLAG_GENERAL_TRAVERSAL everything, go through it: up
+      // to several hundred MB of columns for a deep mesh — is part of the same attempt: if it does not fit, the pass shrinks)
+      const bool generic_all = h->has_deep && (h->gen_all || h->dscene.force_general);
       for (;;) {
         try {
           ensure_workspace(h, (uint64_t)npix * s_chunk, p->max_bounces);
+          if (generic_all) ensure_generic(h, true);
           break;
         } catch (const HipError& e) {
           if (e.e != hipErrorOutOfMemory || s_chunk == 1) throw;
@@ -616,7 +634,6 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           s_chunk = std::max(1u, s_chunk / 2);
         }
       }
-      if (h->has_deep && (h->gen_all || h->dscene.force_general)) ensure_generic(h, true);
       h->accum.alloc((uint64_t)npix * 3);
       HIP_TRY(hipMemsetAsync(h->accum.p, 0, (uint64_t)npix * 3 * sizeof(double), st));
 
@@ -708,7 +725,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     }
     HIP_TRY(hipGetLastError());
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, frame_elems * out_elem, hipMemcpyDeviceToHost, st));
-    uint32_t gen_overflow = 0; // rpt_tree_generic outgrew its columns: they are sized from the scene, so this is a bug, not an input
+    uint32_t gen_overflow = 0; // (the flag rides with the call's last synchronisation; generic_overflowed() is the stand-alone form)
     if (wavefront && h->has_deep && h->gen_overflow.p)
       HIP_TRY(hipMemcpyAsync(&gen_overflow, h->gen_overflow.p, sizeof gen_overflow, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1462,6 +1479,8 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
           for (int k = 0; k < 3; k++) out_normal[3 * (base + i) + k] = hit[(uint64_t)(1 + k) * m + i];
         }
       }
+      if (h->gen_overflow.p && generic_overflowed(h, st))
+        return fail(h, RPTGPU_E_TREE_TOO_DEEP, "rpt_tree_generic: the traversal outgrew the stack sized for this scene (internal error)");
       return RPTGPU_OK;
     }
     DevBuf<double> d_o, d_d, d_t, d_n;

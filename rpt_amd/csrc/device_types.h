@@ -97,8 +97,9 @@ struct alignas(16) Tree {
   uint32_t mesh_kids;   // GROUP: some child is a MESH (a kd-tree of kd-trees): such an object is walked by the per-tree
                         // kernels whatever its own depth (api.cpp)
   uint32_t generic_only; // the tree of a top-level object that only rpt_tree_generic walks (a group among a group's
-                        // children, mesh children rpt_nest_trace does not take, a tree deeper than KD_MAX_STACK):
-                        // rpt_tree_enter hands it every ray
+                        // children, mesh children rpt_nest_trace does not take): rpt_tree_enter hands it every ray.
+                        // (A tree deeper than KD_MAX_STACK is NOT one: rpt_tree_trace takes it, with the levels
+                        // beyond its LDS stack in the spill columns, which api.cpp sizes from the deepest tree.)
   double qlo[3];        // MESH: origin and step of the LeafBox fixed-point grid (coordinate = qlo + q * qscale)
   double qscale[3];
 };

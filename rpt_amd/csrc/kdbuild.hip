@@ -414,8 +414,12 @@ Attempt build_once(const std::vector<double>& soa, size_t n, const Box& root, si
     KD_TRY(rocprim::exclusive_scan(tmp, b2, in, outp, 0ull, count, rocprim::plus<unsigned long long>(), st));
   };
   for (uint32_t depth = 0;; depth++) {
-    if (depth > (uint32_t)rptdev::KD_MAX_STACK + 1) { // the host builder will say so properly (RPTGPU_E_TREE_TOO_DEEP)
-      why = "tree deeper than the device traversal stack";
+    // (no tree is too deep for the traversals since ABI v5 — the per-tree kernels' stacks are sized from the scene's
+    // deepest tree and rpt_tree_generic walks the rest — so the build does not refuse one either.  The bound below only
+    // ends a build that does not converge: the rule halves the primitives of a path every level or stops splitting, so
+    // 64 levels would need 16 * 2^64 / 0.85^64 primitives.)
+    if (depth > 64u) {
+      why = "the device build did not converge (more than 64 levels)";
       return Attempt::failed;
     }
     if (nodes_total + nt > node_cap || leaf_total + ninst > leaf_cap) return Attempt::grow;

@@ -258,6 +258,26 @@ def test_rays_from_a_zero_split_plane_of_either_sign(oracle, order, negative, ro
     assert (ob0 == ob1).all() and (n0.view(np.int64) == n1.view(np.int64)).all()
 
 
+@pytest.mark.parametrize("name", ["dragon", "coverage", "fractal_spheres"])
+def test_scene_options_route_like_the_environment_did(name, monkeypatch):
+    """ABI v6: the routing knobs as RptSceneOptions fields (rptgpu_scene_create_opts) — every tree through the per-tree
+    pipeline, every query sorted, leaf boxes off — give the golden frame like the environment variables of the same
+    names; the handle reports what it runs with, and an environment variable still overrides the struct."""
+    scene, cam, p = small_scenes.small(name)
+    pw = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=_abi.RPT_FLAG_WAVEFRONT)
+    g = GpuScene(scene, 0, deep_depth=1, sort_rays=1, sort_min_rays=0, leaf_boxes=0, paths_chunk=3)
+    o = g.options()
+    assert (o["deep_depth"], o["sort_rays"], o["sort_min_rays"], o["leaf_boxes"], o["paths_chunk"]) == (1, 1, 0, 0, 3)
+    assert (o["sort_min_bytes"], o["workspace_bytes"]) == (8 << 20, 96 << 30)  # untouched fields: the defaults
+    img = g.render_batch(cam, pw)
+    g.close()
+    assert (img == load(name)["image"]).all()
+    monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "5")
+    g = GpuScene(scene, 0, deep_depth=1)
+    assert g.options()["deep_depth"] == 5
+    g.close()
+
+
 @pytest.mark.parametrize("sort", ["0", "1"])
 @pytest.mark.parametrize("name", small_scenes.NAMES)
 def test_per_tree_queries_and_ray_sorting_do_not_change_the_image(name, sort, monkeypatch):
