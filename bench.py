@@ -252,11 +252,32 @@ class Workload:
     def params(self, **kw):
         from rpt_amd import _abi, make_params
         base = 0 if self.args.fixed_samples else self.step_no * self.spp
+        kw.setdefault("collective", _abi.RPT_COLLECTIVE_REDUCE if getattr(self.args, "collective", "gather") == "reduce" else _abi.RPT_COLLECTIVE_GATHER)
         return make_params(self.W, self.H, self.B, self.spp, seed=0x52505447, sample_index_base=base,
                            flags=_abi.RPT_FLAG_PROFILE_KERNELS | self.pipe_flag, **kw)
 
     def close(self):
         self.gpu.close()
+
+
+def committed_n1_line(scene, W, H, B, spp):
+    """The newest committed bench line (profiles/rNN_bench_default.json, profiles/rNN_<scene>_bench_line.json) of the same
+    workload on ONE GPU, for an N-GPU line to carry along; None when there is none.  Informational: a different build."""
+    import glob
+    import re
+    want = "%s %dx%d, %d bounces, %d spp" % (scene, W, H, B, spp)
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")) + glob.glob(os.path.join(ROOT, "profiles", "r*_%s_bench_line.json" % scene)):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        try:
+            d = json.loads(open(path).read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        if not m or d.get("n_gpus") != 1 or not str((d.get("config") or {}).get("workload", "")).startswith(want):
+            continue
+        if best is None or int(m.group(1)) > best[0]:
+            best = (int(m.group(1)), {"ms_per_step": d["ms_per_step"], "value": d["value"], "source": os.path.relpath(path, ROOT)})
+    return best[1] if best else None
 
 
 def accounting(wl, st):
@@ -468,6 +489,8 @@ def main():
     ap.add_argument("--emulate-part-of", type=int, default=0, metavar="N",
                     help="single process: render only the tiles rank 0 would own among N ranks (no collective) and report "
                          "the step time, i.e. the per-rank cost that bounds N-GPU scaling; the JSON line is NOT a bench result")
+    ap.add_argument("--collective", default="gather", choices=["gather", "reduce"],
+                    help="N > 1: how rptgpu_render_batch_reduce brings the ranks' pixels to rank 0 (RptRenderParams::collective)")
     ap.add_argument("--pmc-json", default=None, help="committed rocprofv3 PMC summary to fall back to (default: profiles/<latest>_<scene>_pmc.json)")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -648,7 +671,7 @@ def main():
                        "precision_mode": "strict",
                        "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")),
                        "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
-                       "collective": (("ncclReduce(sum, f32 framebuffer) to rank 0" if os.environ.get("RPTGPU_COLLECTIVE") == "reduce" else
+                       "collective": (("ncclReduce(sum, f32 framebuffer) to rank 0" if (os.environ.get("RPTGPU_COLLECTIVE") or args.collective) == "reduce" else
                                        "gather of the pixels each rank owns (ncclSend / ncclRecv, W*H*12/N bytes per rank) to rank 0")
                                       + " inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else ("torch.distributed reduce (the library's communicator could not be set up: %s)" % collective_note if collective_note else "torch.distributed reduce (gloo stand-in)")) if world > 1 else "none",
                        "timed_region": "render (f64 arithmetic) + gather of the f32 means over the ranks + D2H of the f32 frame to pinned "
@@ -672,6 +695,15 @@ def main():
             "per_rank_is": "HIP-event time per step inside rptgpu_render_batch_reduce on each rank: its own tiles / the gather "
                            "(includes waiting for the slowest rank) / on rank 0 the assembly of the frame and its D2H",
         }
+        if world > 1:
+            # one number for the balance of the partition, and the committed 1-GPU line of the same workload beside it, so
+            # that an N-GPU line can be read on its own (the driver computes the scaling efficiency from its own N = 1 run)
+            rms = [r["render_ms_per_step"] for r in per_rank]
+            out["rank_render_ms"] = {"max": max(rms), "min": min(rms), "max_over_min": max(rms) / max(min(rms), 1e-9),
+                                     "ideal_is": "ms_per_step at N = 1 divided by N"}
+            out["n1_reference"] = committed_n1_line(args.scene, W, H, B, spp)
+            if out["n1_reference"]:
+                out["n1_reference"]["speedup_of_this_line"] = out["n1_reference"]["ms_per_step"] / out["ms_per_step"]
         # ---- the other BASELINE configs on the same clock (1 GPU, default invocation only)
         if default_run and world == 1 and not args.no_other_configs:
             others = []

@@ -52,7 +52,37 @@ def bench_line(log):
     return None
 
 
+def code_object_resources():
+    """VGPRs, spills, scratch and LDS of the library's kernels from the code object's own notes (the compiler's figures:
+    scripts/kernel_resources.py reads the same).  rocprofv3's kernels table reports VGPRs in an allocation unit that
+    halves them on gfx950 (rpt_paths: 128 for 256), and knows nothing of spills."""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.environ.get("RPTGPU_LIB") or os.path.join(ROOT, "rpt_amd", "lib", "librptgpu.so")
+    res = {}
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            import shutil
+            shutil.copy(lib, os.path.join(d, "in.o"))
+            subprocess.run([llvm + "/llvm-objdump", "--offloading", os.path.join(d, "in.o")], cwd=d, check=True, stdout=subprocess.DEVNULL)
+            for co in [os.path.join(d, f) for f in os.listdir(d) if "amdgcn" in f]:
+                t = subprocess.run([llvm + "/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+                for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", t, re.S):
+                    b = m.group(0)
+                    g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1))  # noqa: E731
+                    sym = re.search(r"\.name:\s+(\S+)", b).group(1)
+                    dem = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
+                    res[dem] = {"vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"), "vspill": g("vgpr_spill_count"), "sspill": g("sgpr_spill_count"),
+                                "scratch": g("private_segment_fixed_size"), "lds": g("group_segment_fixed_size"),
+                                "waves_by_vgpr": min(8, 512 // max(8, -(-g("vgpr_count") // 8) * 8))}
+    except Exception as e:  # (no LLVM tools on this box: the columns fall back to rocprofv3's)
+        print("summarize_profile: no code-object notes (%s)" % e, file=sys.stderr)
+    return res
+
+
 rows, regs = [], {}
+notes = code_object_resources()
 c = db("trace")
 if c:
     cur = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels")
@@ -151,10 +181,18 @@ with open(pre + "_summary.md", "w") as f:
                 "(HIP events) — compare with the avg us column below.\n\n"
                 % (d["value"], d["unit"], d["ms_per_step"], k, d["roofline"]["kernels"][k]["avg_ms"]))
         json.dump(d, open(pre + "_bench_line.json", "w"), indent=1)
-    f.write("| kernel | calls | total ms | avg us | % | VGPR | SGPR | scratch B/lane | LDS B |\n|---|---|---|---|---|---|---|---|---|\n")
+    f.write("| kernel | calls | total ms | avg us | % | VGPR | spilled V / S | waves/SIMD by VGPRs | SGPR | scratch B/lane | static LDS B |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
     for s, n, calls, tot, avg, pct in rows:
-        v = regs.get(n, ("", "", "", ""))
-        f.write("| %s | %d | %.2f | %.1f | %.1f | %s | %s | %s | %s |\n" % (re.sub(r"\b\w+::", "", n.split("(")[0]).replace("void ", ""), calls, tot / 1e3, avg, pct, v[0], v[1], v[2], v[3]))
+        key = n if n in notes else next((k for k in notes if k.split("(")[0] == n.split("(")[0]), None)
+        if key:  # the library's own kernels: the compiler's figures
+            r = notes[key]
+            cols = (r["vgpr"], "%d / %d" % (r["vspill"], r["sspill"]), r["waves_by_vgpr"], r["sgpr"], r["scratch"], r["lds"])
+        else:    # runtime / rocPRIM kernels: what rocprofv3 reports (its VGPR unit halves the count on gfx950)
+            v = regs.get(n, ("", "", "", ""))
+            cols = ("%s (rocprofv3)" % v[0] if v[0] != "" else "", "", "", v[1], v[2], v[3])
+        f.write("| %s | %d | %.2f | %.1f | %.1f | %s | %s | %s | %s | %s | %s |\n" % ((re.sub(r"\b\w+::", "", n.split("(")[0]).replace("void ", ""), calls, tot / 1e3, avg, pct) + cols))
+    f.write("\nVGPR, spills, scratch and LDS of the rpt_* kernels: the code object's notes (llvm-readelf --notes of librptgpu.so), "
+            "i.e. the compiler's own report; waves/SIMD by VGPRs = 512 / VGPRs rounded up to 8 (the launch bounds and LDS may allow fewer).\n")
     f.write("\n## Derived per kernel (PMC runs)\n\n| kernel | launches | HBM B/sample | HBM GB/s | of 8 TB/s | VALU busy | lanes/64 | VALU x lanes | wait | L2 hit | VMEM latency |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
     fmt = lambda v, p="%.3g": (p % v) if v is not None else ""  # noqa: E731
     for k in sorted(out["kernels"], key=lambda k: -out["kernels"][k].get("pmc_run_total_us", 0)):
