@@ -49,6 +49,9 @@ pub mod ffi {
     pub const RPT_FLAG_WAVEFRONT: u32 = 2;
     pub const RPT_FLAG_GENERAL_TRAVERSAL: u32 = 4;
     pub const RPT_FLAG_PERSISTENT: u32 = 8;
+    pub const RPT_COLLECTIVE_DEFAULT: u32 = 0;
+    pub const RPT_COLLECTIVE_GATHER: u32 = 1;
+    pub const RPT_COLLECTIVE_REDUCE: u32 = 2;
     pub const RPT_K_COUNT: usize = 8;
     pub const RPTGPU_UNIQUE_ID_BYTES: usize = 128;
 
@@ -442,8 +445,36 @@ impl GpuScene {
         Ok(n)
     }
 
+    /// The back-end's knobs with the library's defaults (`rptgpu_scene_options_default`): change fields, then
+    /// `GpuScene::with_options`.  None of them changes a result.
+    pub fn default_options() -> RptSceneOptions {
+        let mut o = std::mem::MaybeUninit::<RptSceneOptions>::uninit();
+        // SAFETY: the library writes every field of the struct it is given
+        unsafe {
+            ffi::rptgpu_scene_options_default(o.as_mut_ptr());
+            o.assume_init()
+        }
+    }
+
     /// `rptgpu_scene_create`: kd construction by the reference rule (kdtree.rs:235-345), flattening, upload.
     pub fn new(scene: &SceneDesc, device: i32) -> Result<Self, GpuError> {
+        Self::create(scene, device, None)
+    }
+
+    /// `rptgpu_scene_create_opts`: the same with explicit options (ABI v6).
+    pub fn with_options(scene: &SceneDesc, device: i32, options: &RptSceneOptions) -> Result<Self, GpuError> {
+        Self::create(scene, device, Some(options))
+    }
+
+    /// The options the handle runs with: defaults, the caller's, `RPTGPU_*` environment overrides.
+    pub fn options(&self) -> Result<RptSceneOptions, GpuError> {
+        let mut o = Self::default_options();
+        // SAFETY: a live handle and a struct of the library's own size
+        check(unsafe { ffi::rptgpu_scene_get_options(self.h, &mut o) }, self.h)?;
+        Ok(o)
+    }
+
+    fn create(scene: &SceneDesc, device: i32, options: Option<&RptSceneOptions>) -> Result<Self, GpuError> {
         // SAFETY (whole function): every pointer placed in the C description points into `scene`, `low` or the
         // local vectors below, all of which outlive the call; the library copies what it needs.
         if unsafe { ffi::rptgpu_abi_version() } != ffi::RPTGPU_ABI_VERSION {
@@ -502,7 +533,8 @@ impl GpuScene {
             environment,
         };
         let mut h: *mut ffi::rptgpu_scene = std::ptr::null_mut();
-        check(unsafe { ffi::rptgpu_scene_create(&desc, device as c_int, &mut h) }, std::ptr::null())?;
+        let opts = options.map_or(std::ptr::null(), |o| o as *const RptSceneOptions);
+        check(unsafe { ffi::rptgpu_scene_create_opts(&desc, device as c_int, opts, &mut h) }, std::ptr::null())?;
         drop(low);
         Ok(GpuScene { h })
     }
@@ -516,7 +548,7 @@ impl GpuScene {
     }
 
     /// Multi-GPU form (one process per GPU): renders this rank's tiles, gathers the owned pixels on `root` inside the
-    /// library (RCCL send / receive; `RPTGPU_COLLECTIVE=reduce` for an `ncclReduce`) and fills `out_rgb32` on the root rank.
+    /// library (RCCL send / receive; `params.collective = RPT_COLLECTIVE_REDUCE` for an `ncclReduce`) and fills `out_rgb32` on the root rank.
     pub fn render_batch_reduce(&mut self, camera: &RptCamera, params: &RptRenderParams, root: i32, out_rgb32: &mut [f32]) -> Result<(), GpuError> {
         assert_eq!(out_rgb32.len(), params.width as usize * params.height as usize * 3);
         // SAFETY: as above
