@@ -159,7 +159,7 @@ struct rptgpu_scene {
   DevBuf<double> prec;                 // persistent kernel: depth records [threads][bounces][8]
   DevBuf<double> lbuf;                 // persistent kernel: radiance of every sample of a launch [spp][3][npix]
   uint64_t lbuf_max_bytes = 32ull << 30; // cap on lbuf (RPTGPU_LBUF_BYTES); larger batches run as several launches
-  uint32_t paths_chunk = 16;           // samples per work item (RPTGPU_PATHS_CHUNK)
+  uint32_t paths_chunk = 0;            // samples per work item (RptSceneOptions::paths_chunk; 0 = chosen per launch)
   DevBuf<unsigned long long> pcounters; // [0] closest-hit rays [1] shadow rays
   int num_cus = 0;
   bool prefer_wavefront = false; // scene has real kd-trees: traversal-latency bound
@@ -549,7 +549,19 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       uint64_t spp_max = std::max<uint64_t>(1, lbuf_budget / ((uint64_t)npix * 3 * sizeof(double)));
       uint32_t n_launch = (uint32_t)(((uint64_t)p->iterations + spp_max - 1) / spp_max);
       uint32_t spp_l = n_launch ? (p->iterations + n_launch - 1) / n_launch : 0;
-      uint32_t chunk = std::max(1u, std::min(h->paths_chunk, std::max(1u, spp_l)));
+      // Samples per work item.  RptSceneOptions::paths_chunk = 0 (the default) chooses: 16 — 2 for flat scenes that run
+      // the object filter, whose candidate walk lives off the lanes of a wave looking at the same part of the room
+      // (short items keep a wave on one 8x8 pixel block: the 23-polygon room 616 -> 663 Msamples/s; scenes of mostly
+      // one-segment paths lose with short items, glass spheres 4379 -> 3754 at 4) — halved while a lane would get fewer
+      // than 24 items: the launch's tail is one item long (a rank that owns an eighth of a 1080p frame at 128 spp:
+      // x1.056 of the ideal 1/8 with 16 samples per item, x1.014 with 4; profiles/r05_emulated_ranks.txt).
+      uint32_t chunk = h->paths_chunk;
+      if (chunk == 0u) {
+        chunk = (h->all_flat && !h->dscene.force_general && h->flat_layout.obj_filter) ? 2u : 16u;
+        const uint64_t lanes = (uint64_t)std::max(1, h->num_cus) * 8u * 64u;
+        while (chunk > 1u && (uint64_t)npix * ((spp_l + chunk - 1) / chunk) < 24u * lanes) chunk /= 2u;
+      }
+      chunk = std::max(1u, std::min(chunk, std::max(1u, spp_l)));
       uint64_t n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
       // 32-bit work counter: every thread of the grid may fetch once past the end, so items + threads must fit
       const uint64_t item_limit = 0xFFFFFFF0ull - (uint64_t)h->num_cus * 16 * 64;
@@ -798,7 +810,7 @@ void rptgpu_scene_options_default(RptSceneOptions* o) {
   o->object_filter_min = 5;
   o->device_build_min = 32768;
   o->build_threads = 0;
-  o->paths_chunk = 16;
+  o->paths_chunk = 0;
   o->workspace_bytes = 96ull << 30;
   o->lbuf_bytes = 32ull << 30;
   o->target_paths = 0;
@@ -829,7 +841,7 @@ void apply_env_overrides(RptSceneOptions& o) {
   if (ll("RPTGPU_NEST_TRACE", v)) o.nest_trace = v != 0 ? 1 : 0;
   if (ll("RPTGPU_LEAF_BOXES", v)) o.leaf_boxes = v != 0 ? 1 : 0;
   if (ll("RPTGPU_OBJECT_FILTER_MIN", v)) o.object_filter_min = (int32_t)v;
-  if (ll("RPTGPU_PATHS_CHUNK", v)) o.paths_chunk = (uint32_t)std::max(1ll, v);
+  if (ll("RPTGPU_PATHS_CHUNK", v)) o.paths_chunk = (uint32_t)std::max(0ll, v);
   if (ll("RPTGPU_LBUF_BYTES", v) && v >= 24) o.lbuf_bytes = (uint64_t)v;
   if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= 1024) o.target_paths = u; }
   if (const char* e = std::getenv("RPTGPU_WS_BYTES")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= (1ull << 20)) o.workspace_bytes = u; }
@@ -857,7 +869,7 @@ int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOp
       return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "RptSceneOptions::struct_size does not belong to this ABI version (use rptgpu_scene_options_default)");
     std::memcpy(&opt, user_opts, user_opts->struct_size);
     opt.struct_size = (uint32_t)sizeof opt;
-    if (opt.sort_rays < -1 || opt.sort_rays > 1 || opt.deep_depth < 1u || opt.paths_chunk < 1u || opt.lbuf_bytes < 24u ||
+    if (opt.sort_rays < -1 || opt.sort_rays > 1 || opt.deep_depth < 1u || opt.lbuf_bytes < 24u ||
         opt.workspace_bytes < (1ull << 20) || !(opt.comm_timeout_s > 0.0) || (opt.target_paths && opt.target_paths < 1024u))
       return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "RptSceneOptions: a field is out of range");
   }

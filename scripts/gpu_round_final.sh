@@ -1,5 +1,5 @@
 #!/bin/bash
-# the evidence of a round (run through gpurun from the repo root):  TAG=r04 bash scripts/gpu_round_final.sh ["scene:trace_spp:pmc_spp ..."]
+# the evidence of a round (run through gpurun from the repo root):  TAG=r05 bash scripts/gpu_round_final.sh ["scene:trace_spp:pmc_spp ..."]
 #   1. the GPU test suite
 #   2. the DEFAULT bench command (what the driver runs): headline C2 + the other BASELINE configs + live counters
 #   3. rocprofv3 --kernel-trace --stats of the bench command per scene + PMC passes, summarised ON the box (the rocpd
@@ -7,7 +7,7 @@
 #   4. per-phase lane-occupancy tables from the -DRPT_PROF build (rpt_amd/lib/librptgpu_prof.so, if present)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 O=gpurun_out/${TAG}final; mkdir -p $O
 export TMPDIR=/tmp
 export RPT_PROFILE_DST=$REPO/$O/profiles
@@ -34,7 +34,7 @@ timeout 300 python bench.py --scene fractal_teapots --bounces 8 --spp 64 --steps
 TAG=$TAG python - <<'PY'
 import json
 import os
-d=json.load(open("gpurun_out/%sfinal/bench_default.json" % os.environ.get("TAG", "r04")))
+d=json.load(open("gpurun_out/%sfinal/bench_default.json" % os.environ.get("TAG", "r05")))
 r=d["roofline"]
 print("C2 %.1f Msamples/s  %.1f ms/step  frac %.3f (valu_busy %.3f x lanes %.1f/64)  hbm_frac %s  acc_frac %.2f  cpu %.2f  src: %s" % (d["value"], d["ms_per_step"], r.get("frac") or 0, r.get("valu_busy") or 0, r.get("lanes_active") or 0, r.get("hbm_frac"), r.get("accounting_frac") or 0, (d.get("cpu_baseline") or {}).get("value",0), (r.get("pmc_source") or "")[:40]))
 for o in d.get("other_configs",[]):

@@ -56,7 +56,7 @@ def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch
     assert (o.deep_depth, o.fast_max_depth, o.sort_rays, o.rays_in_kernel) == (8, 32, -1, 0)
     assert (o.sort_min_bytes, o.sort_shadow_min_bytes, o.sort_min_rays) == (8 << 20, 32 << 20, 1 << 20)
     assert (o.nest_trace, o.leaf_boxes, o.object_filter_min, o.device_build_min) == (1, 1, 5, 32768)
-    assert (o.build_threads, o.paths_chunk, o.workspace_bytes, o.lbuf_bytes, o.target_paths) == (0, 16, 96 << 30, 32 << 30, 0)
+    assert (o.build_threads, o.paths_chunk, o.workspace_bytes, o.lbuf_bytes, o.target_paths) == (0, 0, 96 << 30, 32 << 30, 0)
     assert o.comm_timeout_s == 300.0
     scene = rpt_amd.Scene()
     scene.add(rpt_amd.Object(rpt_amd.sphere()))
@@ -70,7 +70,7 @@ def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch
     bad = rpt_amd.device.scene_options()
     bad.struct_size = C.sizeof(_abi.RptSceneOptions) + 8
     assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT and b"struct_size" in lib.rptgpu_last_error_detail(None)
-    for field, value in (("sort_rays", 2), ("deep_depth", 0), ("paths_chunk", 0), ("workspace_bytes", 1000),
+    for field, value in (("sort_rays", 2), ("deep_depth", 0), ("lbuf_bytes", 8), ("workspace_bytes", 1000),
                          ("comm_timeout_s", 0.0), ("target_paths", 5)):
         bad = rpt_amd.device.scene_options(**{field: value})
         assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT, field
