@@ -109,7 +109,7 @@ class GpuScene:
 
     def render_batch_reduce(self, camera, params, root=0, out=None):
         """Renderer::sample on every rank: this rank's tiles, the owned pixels gathered on `root` over RCCL
-        (RPTGPU_COLLECTIVE=reduce: ncclReduce(sum) of zero-filled frames), result in host memory on root.  `out`: float32 array of width*height*3 (allocated if None on root)."""
+        (params.collective = RPT_COLLECTIVE_REDUCE: ncclReduce(sum) of zero-filled frames), result in host memory on root.  `out`: float32 array of width*height*3 (allocated if None on root)."""
         cam = camera.lower() if hasattr(camera, "lower") else camera
         if out is None:
             out = np.empty(params.height * params.width * 3, dtype=np.float32)

@@ -780,17 +780,27 @@ def test_gather_and_reduce_give_the_frame_of_a_plain_render(built, monkeypatch):
     scene, cam, p, g = built("cornell")
     pr = make_params(75, 41, p.max_bounces, 3, p.exposure_value, p.seed)
     ref = g.render_batch(cam, pr).astype(np.float32).ravel()
-    for mode in ("gather", "reduce"):
-        monkeypatch.setenv("RPTGPU_COLLECTIVE", mode)
+    for mode in ("gather", "reduce", "param_gather", "param_reduce"):
+        # the exchange's kind through the environment (the override) and through RptRenderParams::collective (ABI v6)
+        pm = pr
+        if mode.startswith("param_"):
+            monkeypatch.delenv("RPTGPU_COLLECTIVE", raising=False)
+            pm = make_params(75, 41, p.max_bounces, 3, p.exposure_value, p.seed,
+                             collective=_abi.RPT_COLLECTIVE_REDUCE if mode.endswith("reduce") else _abi.RPT_COLLECTIVE_GATHER)
+        else:
+            monkeypatch.setenv("RPTGPU_COLLECTIVE", mode)
         g2 = GpuScene(scene, 0)
         g2.comm_init(0, 1, GpuScene.comm_unique_id())
         g2.reset_stats()
-        assert (g2.render_batch_reduce(cam, pr, root=0) == ref).all(), mode
-        assert (g2.render_batch_reduce(cam, pr, root=0) == ref).all(), mode
+        assert (g2.render_batch_reduce(cam, pm, root=0) == ref).all(), mode
+        assert (g2.render_batch_reduce(cam, pm, root=0) == ref).all(), mode
         st = g2.stats()
         assert st.reduce_calls == 2 and st.reduce_render_ms > 0.0 and st.reduce_collective_ms >= 0.0 and st.reduce_copy_ms > 0.0
         g2.close()
-    monkeypatch.delenv("RPTGPU_COLLECTIVE")
+    monkeypatch.delenv("RPTGPU_COLLECTIVE", raising=False)
+    bad = make_params(75, 41, p.max_bounces, 3, p.exposure_value, p.seed, collective=7)
+    with pytest.raises(rpt_amd.RptGpuError):
+        g.render_batch_reduce(cam, bad, root=0)
     for world in (1, 2, 3, 8, 64):
         assert (g.render_batch_emulate_ranks(cam, pr, world) == ref).all(), world
     with pytest.raises(rpt_amd.RptGpuError):
