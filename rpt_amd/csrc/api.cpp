@@ -1006,7 +1006,10 @@ int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOp
       h->gen_all = h->gen_all || all_generic;
       // +8: the sort serves the closest-hit query only
       h->obj_deep.push_back(deep ? (uint8_t)((sort ? 2 : 1) | (all_generic ? 4 : 0) | (sort && !sort_shadow ? 8 : 0)) : 0);
-      h->obj_tris.push_back(trace_kind);
+      // bit 4 (shallow objects): a primitive or a tree that is ONE leaf — runs of such objects take the lean build of
+      // rpt_rays_objects (kernels/wavefront.inc)
+      const bool one_leaf = !tree || fs.trees[in.tree].root_leaf != 0;
+      h->obj_tris.push_back((uint8_t)(trace_kind | (!deep && one_leaf ? 16 : 0)));
       h->has_deep = h->has_deep || deep;
     }
     h->gen_levels = fs.generic_levels; h->gen_frames = fs.generic_frames;
