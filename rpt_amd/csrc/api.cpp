@@ -1122,12 +1122,6 @@ int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOp
           }
         }
       }
-      // room for the walker's prefetched record behind the tables?  (rpt_paths<KdFlat> also keeps its ray stash in the
-      // wave's share, statically)
-      if (off + RPT_PATHS_RECSTAGE_LDS + (lay.n_tris && !lay.obj_filter ? RPT_PATHS_STASH_LDS : 0u) <= WAVE_LDS && !std::getenv("RPTGPU_NO_RECORD_PREFETCH")) {
-        lay.off_recstage = (uint32_t)off;
-        off += RPT_PATHS_RECSTAGE_LDS;
-      }
       lay.off_end = (uint32_t)off;
       if (off > WAVE_LDS) {
         h->all_flat = false;

@@ -36,14 +36,7 @@ struct FlatLayout {
   const rptdev::LeafBox* obj_box; // [objects] in device memory
   const double* obj_grid;        // qlo[3], qscale[3], bounds[6] of the grid, device memory
   uint64_t obj_always;
-  // the fold walker's record, fetched AHEAD: [4][64 lanes][16 B] behind the tables (0 = no room: the walker loads its
-  // record where it needs it).  At the top of every iteration each lane asks for the record its walker will fold at the
-  // END of the iteration — global_load_lds_dwordx4, straight into LDS, no registers — so that the trip to HBM (the ring
-  // of records cycles through 218 MB at C2's grid: nothing of it stays in the L2s) runs under the iteration's work
-  // instead of at its end with nothing to hide behind (kernels/paths.inc; round 5)
-  uint32_t off_recstage;
 };
-#define RPT_PATHS_RECSTAGE_LDS 4096u
 
 // buffers of the optional ray sort in front of a per-tree traversal (all sized for the query's n)
 struct SortBufs {
