@@ -719,10 +719,11 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
                 if (h->light_casts[l] && cnt[2 + l])
                   kt->query(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, cnt[2 + l], l, h->srt.p, ctrs + 2 + l, h->obj_deep.data(), h->obj_tris.data(),
                             h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill, &h->qtune);
-            } else {
+            } else { // one launch for all lights of the depth (the grid's y is the light)
+              uint32_t n_max = 0;
               for (int l = 0; l < nl; l++)
-                if (h->light_casts[l] && cnt[2 + l])
-                  kt->shadow_rays(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, ctrs + 2 + l, cnt[2 + l], l, h->srt.p);
+                if (h->light_casts[l]) n_max = std::max(n_max, cnt[2 + l]);
+              if (n_max) kt->shadow_rays(st, h->dscene, ps, h->shadow_q.p, ctrs + 2, n_max, nl, h->srt.p);
             }
             kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
             b.done();

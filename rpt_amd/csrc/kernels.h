@@ -105,9 +105,10 @@ struct KernelTable {
   void (*shade)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::PathState&,
                 const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters, uint32_t* sq,
                 uint32_t* zero_next /* rpt_shade clears these zero_n words: the next depth's counters */, uint32_t zero_n);
-  // visibility of one light over its shadow-ray queue, whole scene in the kernel (scenes without deep trees)
-  void (*shadow_rays)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* sq,
-                      const uint32_t* sq_count, uint32_t n, int light, double* srt);
+  // visibility of every light of the depth over its shadow-ray queue ([light][cap], lengths sq_counts[light] on the
+  // device, the longest at most n_max), whole scene in the kernel (scenes without deep trees): one launch
+  void (*shadow_rays)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* sq_all,
+                      const uint32_t* sq_counts, uint32_t n_max, int num_lights, double* srt);
   void (*resolve)(hipStream_t, const rptdev::Frame&, const rptdev::PathState&, uint32_t n_samples);
   // means into the full frame, or `packed` into a compact [npix][3] array in the order of Frame::pixels
   void (*finish)(hipStream_t, const rptdev::Frame&, double iterations, double ev_scale, void* out, bool f32, bool packed);
