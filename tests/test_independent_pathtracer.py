@@ -443,3 +443,34 @@ def test_the_cornell_box_and_a_kd_tree_mesh_agree_with_the_independent_path_trac
     assert deep > 0.3 and frac >= 0.99, (frac, same, deep)   # measured: 598 of 600 to 1e-9, 84 % bit for bit, 68 % of the paths three vertices and more
     frac, same, deep = compare(scene_mesh, 48, 36, 4, 500, 77)
     assert deep > 0.2 and frac >= 0.99, (frac, same, deep)
+
+
+def test_python_kd_builder_equals_the_product_builder_node_for_node():
+    """a fourth builder: PyKdTree.construct (sorted(), median, scores — from the Rust text) against rptgpu_kdtree_build
+    (order statistics, threads) on two meshes and on the mixed-sign-zero boxes of tests/test_kdtree.py: the same axis,
+    the same split BITS, the same leaf entries in the same order"""
+    from rpt_amd.device import kdtree_build
+    import small_scenes
+
+    def walk(py, t, idx, count):
+        count[0] += 1
+        if py[0] == "leaf":
+            assert t["info"][idx] & 3 == 3
+            first, n = int(t["a"][idx]), int(t["b"][idx])
+            assert list(t["refs"][first:first + n]) == list(py[1]), idx
+            return
+        ax, value, left, right = py
+        assert int(t["info"][idx]) == ax, idx
+        assert np.float64(value).view(np.uint64) == t["split"][idx:idx + 1].view(np.uint64)[0], (idx, value, t["split"][idx])
+        walk(left, t, int(t["a"][idx]), count)
+        walk(right, t, int(t["a"][idx]) + 1, count)
+
+    cases = [scenes.knot_mesh(64, 12, seed=0x7E57), scenes.lathe_glass_mesh(24)] + \
+            [small_scenes.mixed_zero_mesh(order) for order, _ in small_scenes.MIXED_ZERO_ORDERS]
+    for rows in cases:
+        py = PyKdTree(rows)
+        v = np.asarray(rows)[:, :9].reshape(-1, 3, 3)
+        t = kdtree_build(np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1))
+        count = [0]
+        walk(py.root, t, 0, count)
+        assert count[0] == len(t["split"])
