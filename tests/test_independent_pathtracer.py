@@ -253,13 +253,11 @@ class PyKdTree:
         return 0 if node[0] == "leaf" else 1 + max(self.depth(node[2]), self.depth(node[3]))
 
 
-_TREES = {}
-
-
 def tree_of(shape):
-    if id(shape) not in _TREES:
-        _TREES[id(shape)] = PyKdTree(shape.triangles)
-    return _TREES[id(shape)]
+    """the Python kd-tree of a Mesh, built once and kept ON the shape (an id()-keyed cache would outlive it)"""
+    if getattr(shape, "_py_tree", None) is None:
+        shape._py_tree = PyKdTree(shape.triangles)
+    return shape._py_tree
 
 
 # ------------------------------------------------------------------------------------------------ the glue
