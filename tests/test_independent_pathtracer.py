@@ -67,7 +67,7 @@ def intersect(shape, o, d, t_min, time):
         if hit:
             n = normalize(np.array([(NT[r, 0] * n[0] + NT[r, 1] * n[1]) + NT[r, 2] * n[2] for r in range(3)]))
         return hit, t, n
-    if isinstance(shape, S.KdTree) and shape.triangles is not None:           # a Mesh: the Python kd-tree below
+    if isinstance(shape, S.KdTree):                                           # a Mesh or a group: the Python kd-tree below
         return tree_of(shape).intersect(o, d, t_min, time)
     o1, d1 = o[None, :], d[None, :]
     tm, ti = np.array([t_min]), np.array([time])
@@ -91,7 +91,7 @@ def sample_shape(shape, target, st):
         return G.sphere_sample(target, st)
     if isinstance(shape, S.Cube):
         return G.cube_sample(target, st)
-    if isinstance(shape, S.KdTree) and shape.triangles is not None:
+    if isinstance(shape, S.KdTree):
         return tree_of(shape).sample(target, st)
     raise TypeError(shape)
 
@@ -118,11 +118,18 @@ class PyKdTree:
     longest-extent-first choice), `intersect_subtree` as the reference's recursion (the child boxes by
     BoundingBox::split, six divisions per visited node), the leaf's triangles in index order."""
 
-    def __init__(self, rows):
-        r = np.asarray(rows, float)
-        self.tri = [tuple(r[i, 3 * k:3 * k + 3].copy() for k in range(6)) for i in range(len(r))]
-        self.lo = [np.minimum(np.minimum(t[0], t[1]), t[2]) for t in self.tri]      # Triangle::bounding_box (mesh.rs:40-45)
-        self.hi = [np.maximum(np.maximum(t[0], t[1]), t[2]) for t in self.tri]
+    def __init__(self, rows=None, shapes=None):
+        """rows: (n, 18) triangles — a Mesh; or shapes: bounded shapes — KdTree<Box<dyn Bounded>> (fractal_spheres.rs:45)"""
+        self.shapes = shapes
+        if shapes is not None:
+            self.tri = list(shapes)  # (only its length is used below)
+            boxes = [bounding_box(sh) for sh in shapes]
+            self.lo, self.hi = [b[0] for b in boxes], [b[1] for b in boxes]
+        else:
+            r = np.asarray(rows, float)
+            self.tri = [tuple(r[i, 3 * k:3 * k + 3].copy() for k in range(6)) for i in range(len(r))]
+            self.lo = [np.minimum(np.minimum(t[0], t[1]), t[2]) for t in self.tri]  # Triangle::bounding_box (mesh.rs:40-45)
+            self.hi = [np.maximum(np.maximum(t[0], t[1]), t[2]) for t in self.tri]
         pmin, pmax = np.full(3, math.inf), np.full(3, -math.inf)                      # KdTree::new (kdtree.rs:108-119)
         for a, b in zip(self.lo, self.hi):
             pmin, pmax = np.minimum(pmin, a), np.maximum(pmax, b)
@@ -184,6 +191,11 @@ class PyKdTree:
         return mn, mx
 
     def tri_hit(self, i, o, d, t_min, rec):                                            # Triangle::intersect (mesh.rs:49-82)
+        if self.shapes is not None:  # a group's child: its own Shape::intersect against the shared record
+            h, t, n = intersect(self.shapes[i], o, d, t_min, rec[0])
+            if h:
+                rec[0], rec[1] = t, n
+            return h
         v1, v2, v3, n1, n2, n3 = self.tri[i]
         d0, d1 = v2 - v1, v3 - v1
         pn = np.cross(d0, d1)
@@ -245,7 +257,7 @@ class PyKdTree:
 
     def sample(self, target, st):                                                      # KdTree::sample (kdtree.rs:138-143)
         j = G.uniform_int(st, len(self.tri))
-        v, n, p = G.triangle_sample(self.tri[j], st)
+        v, n, p = sample_shape(self.shapes[j], target, st) if self.shapes is not None else G.triangle_sample(self.tri[j], st)
         return v, n, p / len(self.tri)
 
     def depth(self, node=None):
@@ -253,10 +265,30 @@ class PyKdTree:
         return 0 if node[0] == "leaf" else 1 + max(self.depth(node[2]), self.depth(node[3]))
 
 
+def bounding_box(shape):
+    """Bounded::bounding_box: Sphere (sphere.rs:67-74), Cube (cube.rs:10-17), Transformed<T> (shape.rs:153-176: the eight
+    corners through the matrix, then componentwise min / max)"""
+    if isinstance(shape, S.Sphere):
+        return np.full(3, -1.0), np.full(3, 1.0)
+    if isinstance(shape, S.Cube):
+        return np.full(3, -0.5), np.full(3, 0.5)
+    if isinstance(shape, S.Transformed):
+        lo, hi = bounding_box(shape.shape)
+        M = np.array(shape.transform_m).reshape(4, 4).T
+        pts = []
+        for x in (lo[0], hi[0]):
+            for y in (lo[1], hi[1]):
+                for z in (lo[2], hi[2]):
+                    pts.append(np.array([((M[r, 0] * x + M[r, 1] * y) + M[r, 2] * z) + M[r, 3] * 1.0 for r in range(3)]))
+        pts = np.array(pts)
+        return pts.min(axis=0), pts.max(axis=0)
+    raise TypeError(shape)
+
+
 def tree_of(shape):
-    """the Python kd-tree of a Mesh, built once and kept ON the shape (an id()-keyed cache would outlive it)"""
+    """the Python kd-tree of a Mesh or a group, built once and kept ON the shape (an id()-keyed cache would outlive it)"""
     if getattr(shape, "_py_tree", None) is None:
-        shape._py_tree = PyKdTree(shape.triangles)
+        shape._py_tree = PyKdTree(rows=shape.triangles) if shape.triangles is not None else PyKdTree(shapes=shape.objects)
     return shape._py_tree
 
 
@@ -401,6 +433,14 @@ def scene_mesh():
     return sc, Camera.look_at((0.5, 1.2, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.7)
 
 
+def scene_fractal_spheres():
+    """examples/fractal_spheres.rs at three levels: groups of 1, 5 and 25 placed spheres — the last one a real
+    KdTree<Box<dyn Bounded>> — over a plane, with the example's lights"""
+    sc, cam, _ = scenes.fractal_spheres(levels=3)
+    assert tree_of(sc.objects[2].shape).depth() >= 1
+    return sc, cam
+
+
 def compare(make, width, height, bounces, n_samples, seed):
     sc, cam = make()
     tr = Tracer(sc, cam, width, height, bounces)
@@ -441,6 +481,8 @@ def test_the_cornell_box_and_a_kd_tree_mesh_agree_with_the_independent_path_trac
     assert deep > 0.3 and frac >= 0.99, (frac, same, deep)   # measured: 598 of 600 to 1e-9, 84 % bit for bit, 68 % of the paths three vertices and more
     frac, same, deep = compare(scene_mesh, 48, 36, 4, 500, 77)
     assert deep > 0.2 and frac >= 0.99, (frac, same, deep)
+    frac, same, deep = compare(scene_fractal_spheres, 64, 36, 6, 500, 31)
+    assert deep > 0.2 and frac >= 0.99, (frac, same, deep)
 
 
 def test_python_kd_builder_equals_the_product_builder_node_for_node():
@@ -466,7 +508,7 @@ def test_python_kd_builder_equals_the_product_builder_node_for_node():
     cases = [scenes.knot_mesh(64, 12, seed=0x7E57), scenes.lathe_glass_mesh(24)] + \
             [small_scenes.mixed_zero_mesh(order) for order, _ in small_scenes.MIXED_ZERO_ORDERS]
     for rows in cases:
-        py = PyKdTree(rows)
+        py = PyKdTree(rows=rows)
         v = np.asarray(rows)[:, :9].reshape(-1, 3, 3)
         t = kdtree_build(np.concatenate([v.min(axis=1), v.max(axis=1)], axis=1))
         count = [0]
