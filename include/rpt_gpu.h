@@ -282,7 +282,7 @@ typedef struct RptSceneOptions {
   int32_t sort_rays;              /* RPTGPU_SORT_RAYS (-1): 0 never, 1 every deep tree, -1 by the tree's footprint      */
   int32_t rays_in_kernel;         /* RPTGPU_RAYS_IN_KERNEL (0): rptgpu_closest_hit keeps to one kernel for any scene    */
   uint64_t sort_min_bytes;        /* RPTGPU_SORT_MIN_BYTES (8 MiB): nodes + leaf records of a tree whose rays are sorted */
-  uint64_t sort_shadow_min_bytes; /* RPTGPU_SORT_SHADOW_MIN_BYTES (32 MiB): ... whose SHADOW rays are sorted too         */
+  uint64_t sort_shadow_min_bytes; /* RPTGPU_SORT_SHADOW_MIN_BYTES (8 MiB): ... whose SHADOW rays are sorted too          */
   uint32_t sort_min_rays;         /* RPTGPU_SORT_MIN_RAYS (2^19): queries of fewer rays are not sorted                   */
   int32_t nest_trace;             /* RPTGPU_NEST_TRACE (1): kd-trees of kd-trees in rpt_nest_trace (else rpt_tree_generic) */
   int32_t leaf_boxes;             /* RPTGPU_LEAF_BOXES (1): the conservative f32 box in front of every exact leaf test    */

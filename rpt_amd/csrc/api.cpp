@@ -196,7 +196,7 @@ struct rptgpu_scene {
   uint64_t sort_min_bytes = 8ull << 20;  // RPTGPU_SORT_MIN_BYTES: nodes + leaf records of a tree whose rays are worth sorting
   RptSceneOptions opt{};           // the handle's knobs: defaults, the caller's RptSceneOptions, environment overrides — fixed at creation
   QueryTuning qtune{0u, 1u << 19};  // launch_query's counter-set toggle; opt.sort_min_rays
-  uint64_t sort_shadow_min_bytes = 32ull << 20; // RPTGPU_SORT_SHADOW_MIN_BYTES: ... whose SHADOW rays are, too
+  uint64_t sort_shadow_min_bytes = 8ull << 20; // RPTGPU_SORT_SHADOW_MIN_BYTES: ... whose SHADOW rays are, too
   DevBuf<uint32_t> sort_kin, sort_kout, sort_vin;
   DevBuf<uint8_t> sort_tmp;
   SortBufs sort_bufs{};
@@ -809,7 +809,7 @@ void rptgpu_scene_options_default(RptSceneOptions* o) {
   o->sort_rays = -1;
   o->rays_in_kernel = 0;
   o->sort_min_bytes = 8ull << 20;
-  o->sort_shadow_min_bytes = 32ull << 20;
+  o->sort_shadow_min_bytes = 8ull << 20; // (32 MiB until the visibility queries were sized for the shadow rays there are: sorting 40 % fewer keys, the 16k-triangle glass gains from its shadow sort what it lost before — 756 -> 775 Msamples/s)
   o->sort_min_rays = 1u << 19;
   o->nest_trace = 1;
   o->leaf_boxes = 1;
