@@ -290,8 +290,8 @@ typedef struct RptSceneOptions {
   uint64_t device_build_min;      /* RPTGPU_DEVICE_BUILD_MIN (32768; 4096 when ranks share the host): kd-trees of at least
                                      this many primitives are built on the device; 0 = never                              */
   uint32_t build_threads;         /* RPTGPU_BUILD_THREADS (0 = the usable cores): host threads of the flattening / kd build */
-  uint32_t paths_chunk;           /* RPTGPU_PATHS_CHUNK (0 = per launch: 16, 2 for filtered flat scenes, fewer when a lane
-                                     would get under 24 items): samples per work item of the persistent path kernel       */
+  uint32_t paths_chunk;           /* RPTGPU_PATHS_CHUNK (0 = per launch: 16, 2 for filtered flat scenes at 4+ bounces, fewer
+                                     when a lane would get under 24 items): samples per work item of the persistent path kernel       */
   /* memory */
   uint64_t workspace_bytes;       /* RPTGPU_WS_BYTES (96 GiB): cap of the wavefront pipeline's path state                 */
   uint64_t lbuf_bytes;            /* RPTGPU_LBUF_BYTES (32 GiB): cap of the per-sample radiance buffer of rpt_paths        */

@@ -550,14 +550,16 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       uint32_t n_launch = (uint32_t)(((uint64_t)p->iterations + spp_max - 1) / spp_max);
       uint32_t spp_l = n_launch ? (p->iterations + n_launch - 1) / n_launch : 0;
       // Samples per work item.  RptSceneOptions::paths_chunk = 0 (the default) chooses: 16 — 2 for flat scenes that run
-      // the object filter, whose candidate walk lives off the lanes of a wave looking at the same part of the room
-      // (short items keep a wave on one 8x8 pixel block: the 23-polygon room 616 -> 663 Msamples/s; scenes of mostly
-      // one-segment paths lose with short items, glass spheres 4379 -> 3754 at 4) — halved while a lane would get fewer
+      // the object filter AND trace long paths (max_bounces >= 4): there the lanes of a wave drift apart in path length
+      // and short items keep a wave on one 8x8 pixel block and re-balance it often (the 23-polygon room at 8 bounces
+      // 617 -> 664 Msamples/s, spheres.rs at 6 bounces 1899 -> 1981); with one or two segments per path every sample
+      // costs the same and the per-item bookkeeping is all a short item adds (basic.rs 13418 -> 9391, the simple_video
+      // frame 111 -> 88 frames/s at 2: profiles/r05_paths_chunk_ab.txt) — halved while a lane would get fewer
       // than 24 items: the launch's tail is one item long (a rank that owns an eighth of a 1080p frame at 128 spp:
       // x1.056 of the ideal 1/8 with 16 samples per item, x1.014 with 4; profiles/r05_emulated_ranks.txt).
       uint32_t chunk = h->paths_chunk;
       if (chunk == 0u) {
-        chunk = (h->all_flat && !h->dscene.force_general && h->flat_layout.obj_filter) ? 2u : 16u;
+        chunk = (h->all_flat && !h->dscene.force_general && h->flat_layout.obj_filter && p->max_bounces >= 4u) ? 2u : 16u;
         const uint64_t lanes = (uint64_t)std::max(1, h->num_cus) * 8u * 64u;
         while (chunk > 1u && (uint64_t)npix * ((spp_l + chunk - 1) / chunk) < 24u * lanes) chunk /= 2u;
       }
