@@ -298,6 +298,10 @@ typedef struct RptSceneOptions {
   uint64_t target_paths;          /* RPTGPU_TARGET_PATHS (0 = what the workspace cap holds, at most 128 Mi): paths per pass */
   /* multi-GPU */
   double comm_timeout_s;          /* RPTGPU_COMM_TIMEOUT_S (300): a batch's exchange is given up after this long           */
+  /* routing, added after the first v6 header (struct_size 104): a caller built against that one gets the default */
+  int32_t env_park;               /* RPTGPU_ENV_PARK (1): rpt_paths parks the texture lookups of escaped rays per lane and runs
+                                     them for the wave together; 0 = each on the spot                                       */
+  int32_t _reserved1;             /* 0                                                                               */
 } RptSceneOptions;
 void rptgpu_scene_options_default(RptSceneOptions* out);
 /* opts == NULL: the defaults.  opts->struct_size must be sizeof(RptSceneOptions) of this ABI version (or smaller, of an

@@ -574,7 +574,11 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       const bool flat = h->all_flat && !h->dscene.force_general;
       FlatLayout lay = flat ? h->flat_layout : FlatLayout{};
       const uint32_t flat_lds = lay.off_end;
-      int per_cu = kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds);
+      int per_cu = kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds, false);
+      // a texture environment: the lanes park their lookups in what the wave's LDS share has left (kernels/paths.inc) —
+      // unless that costs a resident wave (a flat scene that fills the share)
+      bool park = h->opt.env_park != 0 && h->dscene.env_kind != RPT_ENV_COLOR;
+      if (park && kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds, true) < per_cu) park = false;
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
       nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
       uint64_t nthreads = (uint64_t)nblocks * 64;
@@ -582,8 +586,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       h->lbuf.alloc(std::max<uint64_t>(1, (uint64_t)spp_l * 3 * npix));
       if (std::getenv("RPTGPU_PRINT_LAUNCH"))
         std::fprintf(stderr, "rpt_paths<%s>: %d blocks/CU x %d CUs -> %u blocks, %u samples per work item, %u launch(es) of %u spp, "
-                     "dynamic LDS %u B per wave (the flat scene's tables)\n",
-                     flat ? (lay.obj_filter ? "KdFlatF" : lay.n_tris ? "KdFlat" : "KdFlatG") : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds);
+                     "dynamic LDS %u B per wave (the flat scene's tables)%s\n",
+                     flat ? (lay.obj_filter ? "KdFlatF" : lay.n_tris ? "KdFlat" : "KdFlatG") : "KdLds", per_cu, h->num_cus, nblocks, chunk, n_launch, spp_l, flat_lds,
+                     park ? " + parked environment lookups" : "");
       h->counters.alloc(4);
       h->pcounters.alloc(16);
       HIP_TRY(hipMemsetAsync(h->pcounters.p, 0, 16 * sizeof(unsigned long long), st));
@@ -598,7 +603,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
         { Bracket b(h, RPT_K_PATHS, prof);
           kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk,
-                    (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, lay, flat, flat_lds);
+                    (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, lay, flat, flat_lds, park);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
       }
@@ -823,6 +828,7 @@ void rptgpu_scene_options_default(RptSceneOptions* o) {
   o->lbuf_bytes = 32ull << 30;
   o->target_paths = 0;
   o->comm_timeout_s = 300.0;
+  o->env_park = 1;
 }
 
 namespace {
@@ -850,6 +856,7 @@ void apply_env_overrides(RptSceneOptions& o) {
   if (ll("RPTGPU_LEAF_BOXES", v)) o.leaf_boxes = v != 0 ? 1 : 0;
   if (ll("RPTGPU_OBJECT_FILTER_MIN", v)) o.object_filter_min = (int32_t)v;
   if (ll("RPTGPU_PATHS_CHUNK", v)) o.paths_chunk = (uint32_t)std::max(0ll, v);
+  if (ll("RPTGPU_ENV_PARK", v)) o.env_park = v != 0 ? 1 : 0;
   if (ll("RPTGPU_LBUF_BYTES", v) && v >= 24) o.lbuf_bytes = (uint64_t)v;
   if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= 1024) o.target_paths = u; }
   if (const char* e = std::getenv("RPTGPU_WS_BYTES")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= (1ull << 20)) o.workspace_bytes = u; }

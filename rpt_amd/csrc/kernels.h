@@ -17,6 +17,12 @@ static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * m
 #define RPT_PATHS_WALKER_LDS 2560u
 // rpt_paths<KdFlat> (a flat scene WITH its triangles in LDS) also keeps the lanes' stashed camera rays there
 #define RPT_PATHS_STASH_LDS 4864u
+// flat scenes with a texture environment: the lanes' queues of parked lookups, RPT_PARK_K entries each, at the end of the
+// wave's dynamic LDS (kernels/paths.inc ParkLds)
+#ifndef RPT_PARK_K
+#define RPT_PARK_K 4
+#endif
+#define RPT_PATHS_PARK_LDS (RPT_PARK_K * 2624u)
 
 // layout of the flat path kernel's dynamic LDS (byte offsets; lrec at 0), see kernels.inc
 struct FlatLayout {
@@ -116,10 +122,12 @@ struct KernelTable {
   void (*scatter_f32)(hipStream_t, const float* src, const uint32_t* pixels, uint32_t n, float* dst);
   void (*eval_math)(hipStream_t, int fn, uint64_t n, const double* x, const double* y, double* out);
   // persistent per-pixel kernel: resident 64-thread blocks per CU, and the launch
-  int (*paths_max_blocks_per_cu)(const FlatLayout* flat /* null: not a flat scene */, uint32_t lds_bytes);
+  // (lds_bytes: the flat scene's tables; park: RPT_PATHS_PARK_LDS more behind them for parked environment lookups)
+  int (*paths_max_blocks_per_cu)(const FlatLayout* flat /* null: not a flat scene */, uint32_t lds_bytes, bool park);
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
-                uint32_t chunk, uint32_t n_items, uint32_t nblocks, const FlatLayout& lay, bool flat, uint32_t lds_bytes);
+                uint32_t chunk, uint32_t n_items, uint32_t nblocks, const FlatLayout& lay, bool flat, uint32_t lds_bytes,
+                bool park);
   // pixel sums of a launch's samples, in sample order
   void (*sum_samples)(hipStream_t, const rptdev::Frame&, const double* lbuf, uint32_t spp, bool first);
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run

@@ -205,6 +205,8 @@ pub mod ffi {
         pub lbuf_bytes: u64,
         pub target_paths: u64,
         pub comm_timeout_s: f64,
+        pub env_park: i32,
+        pub _reserved1: i32,
     }
 
     #[repr(C)]
@@ -624,7 +626,7 @@ mod layout_tests {
         assert_eq!(size_of::<RptScene>(), 80);
         assert_eq!(size_of::<RptCamera>(), 96);
         assert_eq!(size_of::<RptRenderParams>(), 72);
-        assert_eq!(size_of::<RptSceneOptions>(), 104);
+        assert_eq!(size_of::<RptSceneOptions>(), 112);
         assert_eq!(size_of::<RptStats>(), 200);
         assert_eq!(size_of::<RptKdTree>(), 64);
     }

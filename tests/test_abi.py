@@ -57,7 +57,7 @@ def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch
     assert (o.sort_min_bytes, o.sort_shadow_min_bytes, o.sort_min_rays) == (8 << 20, 8 << 20, 1 << 19)
     assert (o.nest_trace, o.leaf_boxes, o.object_filter_min, o.device_build_min) == (1, 1, 5, 32768)
     assert (o.build_threads, o.paths_chunk, o.workspace_bytes, o.lbuf_bytes, o.target_paths) == (0, 0, 96 << 30, 32 << 30, 0)
-    assert o.comm_timeout_s == 300.0
+    assert o.comm_timeout_s == 300.0 and o.env_park == 1
     scene = rpt_amd.Scene()
     scene.add(rpt_amd.Object(rpt_amd.sphere()))
     desc, keep = scene.lower()
@@ -76,6 +76,9 @@ def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch
         assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT, field
     old = rpt_amd.device.scene_options(sort_rays=0)
     old.struct_size = 24  # a caller that knows the first four fields only: the rest keep their defaults
+    assert create(old) == _abi.RPTGPU_E_NO_DEVICE
+    old = rpt_amd.device.scene_options(paths_chunk=4)
+    old.struct_size = 104  # the first v6 header, before env_park
     assert create(old) == _abi.RPTGPU_E_NO_DEVICE
     with pytest.raises(TypeError):
         rpt_amd.device.scene_options(no_such_field=1)

@@ -53,9 +53,25 @@ def test_device_math_is_bit_identical_to_host(oracle, built):
         b = oracle.math_eval(fn, x, y)
         assert (a.view(np.int64) == b.view(np.int64)).all(), fn
     special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-310, 1e300, 0.5, -0.5])
+    # the kernels call the range-converged forms (csrc/math_converged.h): every boundary between two ranges of the five
+    # functions, +- 3 ulps, both signs (the host-side sweep of the same: tests/test_math_converged.py)
+    hi = np.array([0x44100000, 0x3fdc0000, 0x3e200000, 0x3fe60000, 0x3ff30000, 0x40038000, 0x3ff00000, 0x3fe00000, 0x3c600000,
+                   0x40862E42, 0x3fd62e42, 0x3FF0A2B2, 0x3e300000, 0x4002d97c, 0x3fe921fb, 0x3ff921fb, 0x3e400000, 0x3FD33333,
+                   0x3fe90000, 0x40874910, 0x4086232b], dtype=np.uint64)
+    edges = ((hi[:, None, None] << np.uint64(32)) + np.array([0, 1, 0xffffffff], dtype=np.uint64)[None, :, None]
+             + np.arange(-3, 4).astype(np.int64).view(np.uint64)[None, None, :]).ravel()
+    edges = np.concatenate([edges, edges | np.uint64(1 << 63)]).view(np.float64)
+    special = np.concatenate([special, edges])
     for fn in range(6):
         a, b = g.eval_math(fn, special), oracle.math_eval(fn, special)
         assert ((a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))).all(), fn
+    yy, xx = np.meshgrid(special[:80], special[:80])
+    a, b = g.eval_math(6, xx.ravel().copy(), yy.ravel().copy()), oracle.math_eval(6, xx.ravel().copy(), yy.ravel().copy())
+    assert ((a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))).all()
+    y1 = np.concatenate([rs.randn(2048), special])
+    x1 = np.ones(len(y1))
+    a, b = g.eval_math(6, x1, y1), oracle.math_eval(6, x1, y1)  # atan2(y, 1) = atan(y)
+    assert ((a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))).all()
 
 
 def test_shared_reciprocal_division_is_ieee(built):
@@ -276,6 +292,62 @@ def test_scene_options_route_like_the_environment_did(name, monkeypatch):
     g = GpuScene(scene, 0, deep_depth=1)
     assert g.options()["deep_depth"] == 5
     g.close()
+
+
+def _hdri_scene(kind):
+    """glass.rs's pair of spheres, a ring of seven glass / metal / diffuse spheres (the object filter of flat scenes), a
+    glass cube on a polygon with a lamp (a flat scene with its triangles in LDS) — each under a synthetic HDRI"""
+    from rpt_amd import Camera, Environment, Light, Material, Object, Scene, cube, hex_color, polygon, sphere
+    if kind == "glass":
+        return small_scenes.small("glass")
+    scene = Scene()
+    scene.environment = Environment.Hdri(scenes.synthetic_hdri(128, 64, seed=21))
+    if kind == "ring":
+        mats = [Material.clear(1.5, 0.0001), Material.metallic_(hex_color(0xFFFFFF), 0.0001), Material.diffuse(hex_color(0x6F5D48))]
+        for i in range(7):
+            ang = 2.0 * math.pi * i / 7.0
+            scene.add(Object(sphere().scale((0.45, 0.45, 0.45)).translate((1.4 * math.cos(ang), 1.4 * math.sin(ang), -0.3 * i)))
+                      .material(mats[i % 3]))
+        cam = Camera()
+    else:
+        scene.add(Object(cube().scale((0.8, 0.8, 0.8)).rotate_y(0.6).translate((0.0, 0.4, 0.0))).material(Material.clear(1.5, 0.0001)))
+        scene.add(Object(polygon([(-3.0, 0.0, -3.0), (-3.0, 0.0, 3.0), (3.0, 0.0, 3.0), (3.0, 0.0, -3.0)]))
+                  .material(Material.diffuse(hex_color(0x6F5D48))))
+        scene.add(Light.Object(Object(sphere().scale((0.5, 0.5, 0.5)).translate((2.0, 3.0, 1.0)))
+                               .material(Material.light(hex_color(0xFFFFFF), 40.0))))
+        cam = Camera.look_at((2.5, 2.0, 3.5), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 0.7)
+    return scene, cam, make_params(64, 48, 6, 4, seed=130)
+
+
+@pytest.mark.parametrize("kind", ["glass", "ring", "cube"])
+def test_parked_environment_lookups_are_scheduling_only(kind, oracle):
+    """rpt_paths<.., PARK> parks the texture lookups of escaped rays in per-lane queues and drains them for the wave together
+    (RptSceneOptions::env_park, kernels/paths.inc): bit-equal to the oracle with and without, through the three flat
+    instantiations of the persistent kernel, at bounce limits of 1-3 — where the parked paths and the running one press
+    against the record ring's bound — and of 12, with one sample per work item and with sixteen."""
+    scene, cam, p = _hdri_scene(kind)
+    osc = oracle.OracleScene(scene)
+    for bounces, spp in ((p.max_bounces, p.iterations), (1, 16), (2, 16), (3, 16), (12, 8)):
+        pr = make_params(p.width, p.height, bounces, spp, p.exposure_value, p.seed + bounces, flags=_abi.RPT_FLAG_PERSISTENT)
+        ref = osc.render(cam, pr, threads=0)
+        for park, chunk in ((1, 1), (1, 0), (0, 0)):
+            g = GpuScene(scene, 0, env_park=park, paths_chunk=chunk)
+            assert g.options()["env_park"] == park
+            img = g.render_batch(cam, pr)
+            g.close()
+            assert (img == ref).all(), (kind, bounces, park, chunk)
+
+
+@pytest.mark.parametrize("name", ["wine_glass", "monomial_glass", "pegasus", "metal"])
+def test_texture_environments_through_the_other_instantiations(name):
+    # (scenes whose wave has no LDS left for the queues look the environment up on the spot: the fixture's frame either way)
+    scene, cam, p = small_scenes.small(name)
+    for park in (1, 0):
+        g = GpuScene(scene, 0, env_park=park)
+        for flags in (_abi.RPT_FLAG_PERSISTENT, _abi.RPT_FLAG_PERSISTENT | _abi.RPT_FLAG_GENERAL_TRAVERSAL):
+            img = g.render_batch(cam, make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=flags))
+            assert (img == load(name)["image"]).all(), (name, park, flags)
+        g.close()
 
 
 @pytest.mark.parametrize("sort", ["0", "1"])
