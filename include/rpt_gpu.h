@@ -301,7 +301,8 @@ typedef struct RptSceneOptions {
   /* routing, added after the first v6 header (struct_size 104): a caller built against that one gets the default */
   int32_t env_park;               /* RPTGPU_ENV_PARK (1): rpt_paths parks the texture lookups of escaped rays per lane and runs
                                      them for the wave together; 0 = each on the spot                                       */
-  int32_t _reserved1;             /* 0                                                                               */
+  uint32_t paths_batch;           /* RPTGPU_PATHS_BATCH (0 = per launch: 1/32 of a wave's share of the launch's work items, within
+                                     [16, 256]): work items a wave of rpt_paths claims with one atomic on the work counter   */
 } RptSceneOptions;
 void rptgpu_scene_options_default(RptSceneOptions* out);
 /* opts == NULL: the defaults.  opts->struct_size must be sizeof(RptSceneOptions) of this ABI version (or smaller, of an

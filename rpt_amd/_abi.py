@@ -113,7 +113,7 @@ class RptSceneOptions(C.Structure):
                 ("build_threads", C.c_uint32), ("paths_chunk", C.c_uint32),
                 ("workspace_bytes", C.c_uint64), ("lbuf_bytes", C.c_uint64), ("target_paths", C.c_uint64),
                 ("comm_timeout_s", f64),
-                ("env_park", C.c_int32), ("_reserved1", C.c_int32)]
+                ("env_park", C.c_int32), ("paths_batch", C.c_uint32)]
 
 
 class RptStats(C.Structure):

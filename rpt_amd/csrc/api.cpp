@@ -565,8 +565,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       }
       chunk = std::max(1u, std::min(chunk, std::max(1u, spp_l)));
       uint64_t n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
-      // 32-bit work counter: every thread of the grid may fetch once past the end, so items + threads must fit
-      const uint64_t item_limit = 0xFFFFFFF0ull - (uint64_t)h->num_cus * 16 * 64;
+      // 32-bit work counter: every lane of the grid may ask once past the end, and a wave's last guided claim may reach
+      // past it (kernels/paths.inc fetch_item: at most 64 + 256 dead items per wave), so items + 8 x threads must fit
+      const uint64_t item_limit = 0xFFFFFFF0ull - (uint64_t)h->num_cus * 16 * 512;
       if (n_items > item_limit) {
         chunk = (uint32_t)(((uint64_t)spp_l * npix + item_limit - 1) / item_limit);
         while ((n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk)) > item_limit) chunk++;
@@ -603,7 +604,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(uint32_t), st));
         { Bracket b(h, RPT_K_PATHS, prof);
           kt->paths(st, h->dscene, fr, cam, h->counters.p, h->prec.p, h->pcounters.p, h->lbuf.p, spp, chunk,
-                    (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, lay, flat, flat_lds, park);
+                    (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, lay, flat, flat_lds, park, h->opt.paths_batch);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
       }
@@ -857,6 +858,7 @@ void apply_env_overrides(RptSceneOptions& o) {
   if (ll("RPTGPU_OBJECT_FILTER_MIN", v)) o.object_filter_min = (int32_t)v;
   if (ll("RPTGPU_PATHS_CHUNK", v)) o.paths_chunk = (uint32_t)std::max(0ll, v);
   if (ll("RPTGPU_ENV_PARK", v)) o.env_park = v != 0 ? 1 : 0;
+  if (ll("RPTGPU_PATHS_BATCH", v)) o.paths_batch = (uint32_t)std::max(0ll, std::min(v, 65536ll));
   if (ll("RPTGPU_LBUF_BYTES", v) && v >= 24) o.lbuf_bytes = (uint64_t)v;
   if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= 1024) o.target_paths = u; }
   if (const char* e = std::getenv("RPTGPU_WS_BYTES")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= (1ull << 20)) o.workspace_bytes = u; }

@@ -127,7 +127,7 @@ struct KernelTable {
   void (*paths)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::Camera&,
                 uint32_t* work_counter, double* rec, unsigned long long* ray_counters, double* lbuf, uint32_t spp,
                 uint32_t chunk, uint32_t n_items, uint32_t nblocks, const FlatLayout& lay, bool flat, uint32_t lds_bytes,
-                bool park);
+                bool park, uint32_t batch /* work items a wave claims at a time; 0 = by the launch's size */);
   // pixel sums of a launch's samples, in sample order
   void (*sum_samples)(hipStream_t, const rptdev::Frame&, const double* lbuf, uint32_t spp, bool first);
   // deep-tree scenes: one closest-hit (light < 0) or visibility (light >= 0) query of a depth, run

@@ -206,7 +206,7 @@ pub mod ffi {
         pub target_paths: u64,
         pub comm_timeout_s: f64,
         pub env_park: i32,
-        pub _reserved1: i32,
+        pub paths_batch: u32,
     }
 
     #[repr(C)]

@@ -294,6 +294,23 @@ def test_scene_options_route_like_the_environment_did(name, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("batch", [1, 7, 256])
+@pytest.mark.parametrize("name", ["cornell", "glass", "spheres", "simple_video"])
+def test_work_item_pools_are_scheduling_only(name, batch):
+    """A wave of rpt_paths claims work items in batches (RptSceneOptions::paths_batch, kernels/paths.inc fetch_item): one
+    at a time as before round 5, an odd size, more than the frame has items per wave — the fixture's frame, and every
+    sample rendered exactly once (the sample count of the stats)."""
+    scene, cam, p = small_scenes.small(name)
+    g = GpuScene(scene, 0, paths_batch=batch, paths_chunk=1 if batch == 7 else 0)
+    assert g.options()["paths_batch"] == batch
+    g.reset_stats()
+    img = g.render_batch(cam, make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed,
+                                          flags=_abi.RPT_FLAG_PERSISTENT))
+    assert (img == load(name)["image"]).all(), (name, batch)
+    assert g.stats().samples == p.width * p.height * p.iterations
+    g.close()
+
+
 def _hdri_scene(kind):
     """glass.rs's pair of spheres, a ring of seven glass / metal / diffuse spheres (the object filter of flat scenes), a
     glass cube on a polygon with a lamp (a flat scene with its triangles in LDS) — each under a synthetic HDRI"""
