@@ -14,7 +14,7 @@ export RPT_PROFILE_DST=$REPO/$O/profiles
 mkdir -p $RPT_PROFILE_DST
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
-LIST=${1:-"cornell:0:512 dragon:32:16 wine_glass:8:4 fractal_spheres:8:4 room23:64:64"}
+LIST=${1:-"cornell:0:512 dragon:32:16 wine_glass:8:4 fractal_spheres:8:4 room23:64:64 glass:64:64"}
 for item in $LIST; do
   IFS=: read sc tspp pspp <<< "$item"
   bash scripts/profile.sh $TAG $sc $tspp $pspp "--no-live-pmc" > $O/profile_$sc.log 2>&1
@@ -23,7 +23,7 @@ for item in $LIST; do
 done
 P=$PWD/rpt_amd/lib/librptgpu_prof.so
 if [ -f $P ]; then
-  for sc in "cornell 64" "room23 32" "dragon 16" "wine_glass 4" "fractal_spheres 4" "fractal_teapots 16 --bounces 8"; do
+  for sc in "cornell 64" "room23 32" "glass 16" "dragon 16" "wine_glass 4" "fractal_spheres 4" "fractal_teapots 16 --bounces 8"; do
     set -- $sc
     echo "## $1, $2 spp, 1 step (bench.py --scene $1 --steps 1 --warmup 0 --spp $2 $3 $4, librptgpu_prof.so = -DRPT_PROF build)" >> $O/phase_tables.txt
     RPTGPU_LIB=$P RPTGPU_PRINT_PHASES=1 timeout 300 python bench.py --scene $1 --steps 1 --warmup 0 --spp $2 $3 $4 --no-cpu-baseline --no-live-pmc 2>&1 >/dev/null | grep "^prof" >> $O/phase_tables.txt
