@@ -578,7 +578,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       int per_cu = kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds, false);
       // a texture environment: the lanes park their lookups in what the wave's LDS share has left (kernels/paths.inc) —
       // unless that costs a resident wave (a flat scene that fills the share)
-      bool park = h->opt.env_park != 0 && h->dscene.env_kind != RPT_ENV_COLOR;
+      bool park = flat && h->opt.env_park != 0 && h->dscene.env_kind != RPT_ENV_COLOR; // (flat scenes: rpt_paths<KdLds>'s stack fills the share)
       if (park && kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds, true) < per_cu) park = false;
       uint32_t nblocks = (uint32_t)std::max(1, h->num_cus * per_cu);
       nblocks = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, (n_items + 63) / 64));
