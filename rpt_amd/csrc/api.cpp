@@ -887,7 +887,8 @@ int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOp
     std::memcpy(&opt, user_opts, user_opts->struct_size);
     opt.struct_size = (uint32_t)sizeof opt;
     if (opt.sort_rays < -1 || opt.sort_rays > 1 || opt.deep_depth < 1u || opt.lbuf_bytes < 24u ||
-        opt.workspace_bytes < (1ull << 20) || !(opt.comm_timeout_s > 0.0) || (opt.target_paths && opt.target_paths < 1024u))
+        opt.workspace_bytes < (1ull << 20) || !(opt.comm_timeout_s > 0.0) || (opt.target_paths && opt.target_paths < 1024u) ||
+        opt.paths_batch > 65536u)
       return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "RptSceneOptions: a field is out of range");
   }
   apply_env_overrides(opt);

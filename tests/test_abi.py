@@ -71,7 +71,7 @@ def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch
     bad.struct_size = C.sizeof(_abi.RptSceneOptions) + 8
     assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT and b"struct_size" in lib.rptgpu_last_error_detail(None)
     for field, value in (("sort_rays", 2), ("deep_depth", 0), ("lbuf_bytes", 8), ("workspace_bytes", 1000),
-                         ("comm_timeout_s", 0.0), ("target_paths", 5)):
+                         ("comm_timeout_s", 0.0), ("target_paths", 5), ("paths_batch", 1 << 20)):
         bad = rpt_amd.device.scene_options(**{field: value})
         assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT, field
     old = rpt_amd.device.scene_options(sort_rays=0)
