@@ -10,15 +10,20 @@ through the last bounce, the reduce over ranks, and the write of the W*H mean co
 (strong scaling) and rank 0 gathers the f32 pixels each rank owns, one RCCL send / receive group per step.
 
     python bench.py                      # 1 GPU: the headline (C2) + the other BASELINE configs + live counters
+    python bench.py --gpus N --steps K --warmup W    # N GPUs: bench.py starts its own N ranks (torch.distributed.run,
+                                                     # one per GPU); fewer than N visible devices is an error
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # the same under an outer launcher
     python bench.py --scene dragon --spp 16          # another BASELINE config at ITS frame size, nothing else
     python bench.py --scene simple_video             # scene rebuilt per frame (examples/simple_video.rs): frames/s
 
 The default 1-GPU run prints ONE JSON line.  Besides the headline it carries
-  * `other_configs`: BASELINE configs[2-4] (dragon-class mesh, fractal spheres, wine glass — mesh and glass-spheres
-    variants) at their own frame sizes and >= 16 spp per step (cost per sample does not depend on spp), 3 steps +
-    1 warm-up each, each with its own roofline object and CPU baseline (>= 16 spp, median of 3 repetitions);
+  * `other_configs`: BASELINE configs[2-4] (dragon-class mesh at its 256 spp, fractal spheres, wine glass — mesh and
+    glass-spheres variants) at their own frame sizes and >= 16 spp per step (cost per sample does not depend on spp),
+    5 steps + 1 warm-up each with median / min / max, each with its own roofline object and CPU baseline (>= 16 spp,
+    median of 3 repetitions); their values again as top-level scalars (`c3_msamples`, `c4_msamples`, ...).  At N > 1
+    the two configs BASELINE assigns to 8 GPUs (fractal spheres, wine-glass mesh) run through the same sharded path
+    at 64 spp per step, and `exchange` says whether the library's RCCL exchange moved frames in this run;
   * `roofline` objects whose counter fields (VALU busy, lanes active per VALU instruction, HBM bytes, L2 requests)
     are measured IN THIS RUN: bench.py re-runs one step of each workload under `rocprofv3 --pmc ... --kernel-trace`
     in a child process (no torch, ~10 s per pass) and reads the counters back.  If rocprofv3 is not usable the
@@ -49,10 +54,12 @@ ENV = 4 * 32
 FB = 24
 
 # the other BASELINE configs in the default run: (scene, spp per step).  Frame size and bounces are the config's own.
-# (>= 16 spp, 3 steps + 1 warm-up each; the glass SPHERES variant of C5 — examples/glass.rs — renders 64 spp per step:
-# its step would otherwise be 30 ms)
-OTHER_CONFIGS = (("dragon", 32), ("fractal_spheres", 16), ("wine_glass", 16), ("glass", 64))
-OTHER_STEPS, OTHER_WARMUP = 3, 1
+# (C3 at its BASELINE 256 spp — it fits one GPU; the 4K configs at >= 16 spp; 5 steps + 1 warm-up each, median and
+# min / max on the line; the glass SPHERES variant of C5 — examples/glass.rs — renders 64 spp per step: its step would
+# otherwise be 30 ms)
+OTHER_CONFIGS = (("dragon", 256), ("fractal_spheres", 16), ("wine_glass", 16), ("glass", 64))
+OTHER_STEPS, OTHER_WARMUP = 5, 1
+PMC_MAX_SPP = 32  # the counter pass of a secondary config renders at most this many spp (the counters are ratios)
 CPU_MIN_SPP, CPU_REPS = 16, 3
 PMC_A = "FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
 PMC_B = "WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM"
@@ -377,10 +384,11 @@ def roofline_object(wl, st, kernels, dominant, kern_n, bytes_k, pmc, pmc_note, p
     rank_samples = float(st.samples)
     acc = kernels[dominant]["accounting_GBs"]
     roof = {"bound": "valu", "kernel": dominant, "unit": "Tlane-slot/s (f64 VALU: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2)",
-            "peak": VALU_F64_PEAK_TLANES, "achieved": None, "frac": None, "traffic": None,
+            "peak": VALU_F64_PEAK_TLANES, "achieved": None, "frac": None, "frac_kind": "valu_lane_slots", "traffic": None,
             "frac_is": "VALU busy x lanes active / 64 of the dominant kernel (SQ counters of this run): the share of the f64 "
                        "lane slots that did work.  NOT bytes / HBM peak — that figure is accounting_frac below",
             "accounting_GBs": acc, "accounting_frac": (acc / HBM_PEAK_GBS) if acc else None,
+            "accounting_frac_kind": "survey_8d_reference_bytes_over_hbm_peak (not headroom: served from registers / LDS / L2)",
             "accounting_is": "SURVEY §8d: algorithmic bytes of the REFERENCE traversal x units / launch time / 8 TB/s.  The bytes "
                              "are served from registers, LDS and L2 (hbm_frac is the measured HBM share) and partly never "
                              "touched (leaf-box filter, untraced zero-contribution shadow rays): exceeds 1 when cache-served",
@@ -469,6 +477,179 @@ def run_simple_video(args, local_rank):
                                  "python_scene_build_ms_mean": (total - t_create - t_render) / frames * 1e3}}))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (the driver's form): start N ranks of this file under
+    torch.distributed.run, one per GPU, and hand their output through.  Fewer than N visible devices is an error, not a
+    smaller run (RPT_BENCH_BACKEND=gloo, the tests' stand-in, lets ranks share a device)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if os.environ.get("RPT_BENCH_BACKEND", "nccl") == "nccl" and have < args.gpus:
+        print("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to run a smaller job under the same name"
+              % (args.gpus, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RPT_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class Ranks:
+    """this process among the ranks of the job"""
+
+    def __init__(self, rank, world, local_rank, backend, force_lib):
+        import torch
+        self.rank, self.world, self.local_rank, self.backend, self.force_lib = rank, world, local_rank, backend, force_lib
+        self.dev = torch.device("cuda", local_rank)
+        self.cdev = self.dev if backend == "nccl" else torch.device("cpu")  # where the control-plane tensors live
+
+    def fence(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def setup_exchange(rk, wl):
+    """How this workload's frames reach rank 0.  The collective lives in the library (rptgpu_comm_init /
+    rptgpu_render_batch_reduce: ncclSend / ncclRecv or ncclReduce on the library's stream, then D2H on rank 0), so no torch
+    op sits in the timed path.  Only the gloo stand-in used by the tests (several ranks sharing one GPU, which RCCL
+    refuses) goes through torch.distributed.  Returns (step, lib_collective, note, host_frame)."""
+    import torch
+    import torch.distributed as dist
+    import rpt_amd
+    from rpt_amd import distributed as D
+    rank, world, gpu, camera = rk.rank, rk.world, wl.gpu, wl.camera
+    host_frame = torch.empty(wl.W * wl.H * 3, dtype=torch.float32).pin_memory()
+    host_np = host_frame.numpy()
+    lib_collective = world == 1 or rk.backend == "nccl" or rk.force_lib
+    note = None
+    if lib_collective and world > 1:
+        # Step 1, local and cheap: can THIS rank open RCCL from the library at all?  Agreed on by every rank BEFORE anyone
+        # enters ncclCommInitRank — a rank that cannot would otherwise leave the others blocked in the rendezvous.
+        ok = 1
+        try:
+            rpt_amd.GpuScene.comm_unique_id()
+        except Exception as e:
+            ok, note = 0, "%s: %s" % (type(e).__name__, e)
+        agreed = torch.tensor([ok], dtype=torch.int32, device=rk.cdev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 1:
+            # Step 2: the communicator.  ncclCommInitRank either succeeds or fails on every rank (it is itself a rendezvous)
+            try:
+                uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0, device=rk.cdev)
+                gpu.comm_init(rank, world, uid[0])
+            except Exception as e:
+                ok, note = 0, "%s: %s" % (type(e).__name__, e)
+            agreed = torch.tensor([ok], dtype=torch.int32, device=rk.cdev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:  # say why, and let torch's RCCL do the reduce
+            if ok:
+                gpu.comm_destroy()
+            notes = [None] * world
+            dist.all_gather_object(notes, note)
+            note = next((x for x in notes if x), "rptgpu_comm_init failed on another rank")
+            lib_collective = False
+            if rank == 0:
+                print("bench: library collective unavailable (%s); reducing through torch.distributed" % note, file=sys.stderr)
+    frame = None if lib_collective else torch.zeros(wl.W * wl.H * 3, dtype=torch.float32, device=rk.dev)
+    render_part = None if lib_collective else D.gpu_render_part(gpu, camera)
+
+    def step():
+        p = wl.params()
+        if lib_collective:
+            # Renderer::sample on every rank; ends with the colours in host memory on rank 0 (renderer.rs:127-128)
+            gpu.render_batch_reduce(camera, p, root=0, out=host_np)
+        else:
+            D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
+            if rank == 0:
+                host_frame.copy_(frame, non_blocking=False)
+        wl.step_no += 1
+
+    return step, lib_collective, note, host_frame
+
+
+def timed_steps(rk, wl, step, steps, warmup):
+    """warmup untimed steps, then EXACTLY `steps` steps between two fences (barrier + device synchronize on both sides);
+    the MAX over ranks of that time.  Every step is also clocked on its own on this rank (a step is synchronous: it
+    returns when the frame is in host memory on rank 0), for the median / min / max beside the mean."""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    rk.fence()
+    wl.gpu.reset_stats()
+    each = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        step()
+        each.append((time.perf_counter() - t1) * 1e3)
+    rk.fence()
+    elapsed = time.perf_counter() - t0
+    if rk.world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rk.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = wl.gpu.stats()
+    # what each rank spent where (HIP events inside rptgpu_render_batch_reduce), and the rays it traced
+    mine = {"rank": rk.rank, "render_ms_per_step": st.reduce_render_ms / max(1, st.reduce_calls),
+            "collective_ms_per_step": st.reduce_collective_ms / max(1, st.reduce_calls),
+            "copy_ms_per_step": st.reduce_copy_ms / max(1, st.reduce_calls),
+            "library_exchange_calls_completed": int(st.reduce_calls),
+            "extend_rays": int(st.extend_rays), "shadow_rays": int(st.shadow_rays), "shadow_rays_traced": int(st.shadow_rays_traced),
+            "scene_create_ms": wl.scene_create_ms}
+    per_rank = [mine]
+    if rk.world > 1:
+        per_rank = [None] * rk.world
+        dist.all_gather_object(per_rank, mine)
+    return elapsed, each, st, per_rank
+
+
+def step_spread(each, samples_per_step):
+    """median / min / max of the per-step clocks, as ms and as Msamples/s"""
+    s = sorted(each)
+    med = s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+    return {"ms_median": med, "ms_min": s[0], "ms_max": s[-1],
+            "msamples_median": samples_per_step / med / 1e3, "msamples_min": samples_per_step / s[-1] / 1e3,
+            "msamples_max": samples_per_step / s[0] / 1e3,
+            "is": "each of the timed steps clocked on its own on rank 0 (a step returns when its frame is in host memory)"}
+
+
+def exchange_evidence(rk, lib_collective, note, per_rank):
+    """Has the library's own exchange (ncclSend / ncclRecv or ncclReduce inside rptgpu_render_batch_reduce) moved frames
+    between devices IN THIS RUN?  Stated on the line because it has never been possible to try before the first multi-GPU
+    run (one GPU per box in every development round)."""
+    if rk.world == 1:
+        return {"ranks": 1, "library_exchange_ran": False, "why": "one rank: nothing to exchange"}
+    calls = [r["library_exchange_calls_completed"] for r in per_rank]
+    ran = bool(lib_collective and rk.backend == "nccl" and min(calls) > 0)
+    return {"ranks": rk.world, "backend": rk.backend, "library_exchange_ran": ran,
+            "calls_completed_per_rank": calls,
+            "why": ("rptgpu_render_batch_reduce returned success on every rank for every timed step: RCCL moved the ranks' "
+                    "pixels to rank 0 inside the library" if ran else
+                    ("the library's communicator could not be set up (%s): torch.distributed reduced the frames" % note if note else
+                     "gloo stand-in (ranks share a device): torch.distributed reduced the frames, the library's RCCL path did not run"))}
+
+
+# the secondary configs an N > 1 run times through the same sharded path: the two BASELINE assigns to 8 GPUs, at >= 64 spp
+# per step (at 16 spp the wavefront pipeline's per-depth fixed costs are x1.6-1.8 of the ideal 1/N per rank,
+# profiles/r05_emulated_ranks.txt)
+MULTI_GPU_OTHER_CONFIGS = (("fractal_spheres", 64), ("wine_glass", 64))
+MULTI_GPU_OTHER_STEPS, MULTI_GPU_OTHER_WARMUP = 3, 1
+SCALAR_KEYS = {"dragon": "c3_msamples", "fractal_spheres": "c4_msamples", "wine_glass": "c5_mesh_msamples", "glass": "c5_glass_spheres_msamples"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -498,19 +679,25 @@ def main():
     args.scene = args.scene or "cornell"
     if args.pmc_worker:
         return pmc_worker(args)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # no launcher around us: be our own (one rank per GPU, this file again)
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import rpt_amd
     from rpt_amd import _abi, make_params, scenes
-    from rpt_amd import distributed as D
     if args.scene not in scenes.SCENES:
         ap.error("unknown scene %r (known: %s)" % (args.scene, ", ".join(sorted(scenes.SCENES))))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # never a smaller (or larger) job than the one asked for under the same name
+        print("bench.py: --gpus %d does not match the launcher's WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # RPT_BENCH_BACKEND=gloo lets the N>1 logic be exercised with several ranks on ONE GPU
     # (ranks share device local_rank % device_count); the driver's runs use nccl = RCCL.
     backend = os.environ.get("RPT_BENCH_BACKEND", "nccl")
@@ -519,85 +706,32 @@ def main():
     if os.environ.get("RPT_BENCH_FAIL_COMM_RANK", "") == str(rank):
         os.environ["RPTGPU_FAIL_COMM"] = "1"
     force_lib = os.environ.get("RPT_BENCH_FORCE_LIB_COLLECTIVE", "") == "1"
-    local_rank = local_rank % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > 1 and ndev < world:
+        print("bench.py: %d ranks, %d HIP device(s) visible: RCCL needs one device per rank" % (world, ndev), file=sys.stderr)
+        sys.exit(2)
+    local_rank = local_rank % max(1, ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, "--gpus must match the launcher's world size"
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rk = Ranks(rank, world, local_rank, backend, force_lib)
+    dev = rk.dev
     if args.scene == "simple_video" and world == 1:
         return run_simple_video(args, local_rank)
 
     torch.cuda.synchronize()
     wl = Workload(args.scene, args, rank, world, local_rank, backend)
     W, H, B, spp, gpu, camera = wl.W, wl.H, wl.B, wl.spp, wl.gpu, wl.camera
-    host_frame = torch.empty(W * H * 3, dtype=torch.float32).pin_memory()
-    host_np = host_frame.numpy()
-    # The collective lives in the library (rptgpu_comm_init / rptgpu_render_batch_reduce: ncclReduce on the library's
-    # stream, then D2H on rank 0), so no torch op sits in the timed path.  Only the gloo stand-in used by the tests
-    # (several ranks sharing one GPU, which RCCL refuses) goes through torch.distributed.
-    lib_collective = world == 1 or backend == "nccl" or force_lib
-    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the few control-plane tensors of the set-up live
-    collective_note = None
-    if lib_collective and world > 1:
-        # Step 1, local and cheap: can THIS rank open RCCL from the library at all?  Agreed on by every rank BEFORE anyone
-        # enters ncclCommInitRank — a rank that cannot would otherwise leave the others blocked in the rendezvous.
-        ok = 1
-        try:
-            rpt_amd.GpuScene.comm_unique_id()
-        except Exception as e:
-            ok, collective_note = 0, "%s: %s" % (type(e).__name__, e)
-        agreed = torch.tensor([ok], dtype=torch.int32, device=cdev)
-        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed.item()) == 1:
-            # Step 2: the communicator.  ncclCommInitRank either succeeds or fails on every rank (it is itself a rendezvous)
-            try:
-                uid = [rpt_amd.GpuScene.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0, device=cdev)
-                gpu.comm_init(rank, world, uid[0])
-            except Exception as e:
-                ok, collective_note = 0, "%s: %s" % (type(e).__name__, e)
-            agreed = torch.tensor([ok], dtype=torch.int32, device=cdev)
-            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed.item()) == 0:  # say why, and let torch's RCCL do the reduce
-            if ok:
-                gpu.comm_destroy()
-            notes = [None] * world
-            dist.all_gather_object(notes, collective_note)
-            collective_note = next((x for x in notes if x), "rptgpu_comm_init failed on another rank")
-            lib_collective = False
-            if rank == 0:
-                print("bench: library collective unavailable (%s); reducing through torch.distributed" % collective_note,
-                      file=sys.stderr)
-    frame = None if lib_collective else torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
-    render_part = None if lib_collective else D.gpu_render_part(gpu, camera)
-
-    def step():
-        p = wl.params()
-        if lib_collective:
-            # Renderer::sample on every rank; ends with the colours in host memory on rank 0 (renderer.rs:127-128)
-            gpu.render_batch_reduce(camera, p, root=0, out=host_np)
-        else:
-            D.render_frame_sharded(render_part, p, rank, world, frame, dst=0)
-            if rank == 0:
-                host_frame.copy_(frame, non_blocking=False)
-        wl.step_no += 1
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     if args.emulate_part_of > 1 and world == 1:
         import ctypes as C
         dframe = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
 
-        def step():  # noqa: F811 — what one of N ranks does between the collectives
+        def step():  # what one of N ranks does between the collectives
             p = wl.params(tile=(32, 8), part=(0, args.emulate_part_of))
             cam = camera.lower()
             _abi.check(gpu.lib.rptgpu_render_batch_device(gpu.handle, C.byref(cam), C.byref(p), C.c_void_p(dframe.data_ptr()), 1, None), gpu.handle)
@@ -615,35 +749,14 @@ def main():
         gpu.close()
         return
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    gpu.reset_stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    st = gpu.stats()
-    # what each rank spent where (HIP events inside rptgpu_render_batch_reduce), and the rays it traced
-    mine = {"rank": rank, "render_ms_per_step": st.reduce_render_ms / max(1, st.reduce_calls),
-            "collective_ms_per_step": st.reduce_collective_ms / max(1, st.reduce_calls),
-            "copy_ms_per_step": st.reduce_copy_ms / max(1, st.reduce_calls),
-            "extend_rays": int(st.extend_rays), "shadow_rays": int(st.shadow_rays), "shadow_rays_traced": int(st.shadow_rays_traced),
-            "scene_create_ms": wl.scene_create_ms}
-    per_rank = [mine]
-    if world > 1:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+    step, lib_collective, collective_note, host_frame = setup_exchange(rk, wl)
+    elapsed, each, st, per_rank = timed_steps(rk, wl, step, args.steps, args.warmup)
     rays_traced = float(sum(r["extend_rays"] + r["shadow_rays_traced"] for r in per_rank))
     rays_reference = float(sum(r["extend_rays"] + r["shadow_rays"] for r in per_rank))
 
     if rank == 0 and args.dump_frame:
         np.save(args.dump_frame, host_frame.numpy())
+    out = None
     if rank == 0:
         total_samples = float(W) * H * spp * args.steps
         value = total_samples / elapsed / 1e6
@@ -671,6 +784,8 @@ def main():
                        "precision_mode": "strict",
                        "pipeline": args.pipeline + ("" if args.pipeline != "auto" else " -> " + ("persistent" if kern_n.get("rpt_paths", 0) else "wavefront")),
                        "partition": "interleaved 32x8 tiles, tile_id %% %d == rank" % world,
+                       "launched_by": "bench.py itself (torch.distributed.run, one rank per GPU)" if os.environ.get("RPT_BENCH_SELF_LAUNCHED") else
+                                      ("an outer launcher (WORLD_SIZE in the environment)" if world > 1 else "single process"),
                        "collective": (("ncclReduce(sum, f32 framebuffer) to rank 0" if (os.environ.get("RPTGPU_COLLECTIVE") or args.collective) == "reduce" else
                                        "gather of the pixels each rank owns (ncclSend / ncclRecv, W*H*12/N bytes per rank) to rank 0")
                                       + " inside librptgpu (rptgpu_render_batch_reduce)" if lib_collective else ("torch.distributed reduce (the library's communicator could not be set up: %s)" % collective_note if collective_note else "torch.distributed reduce (gloo stand-in)")) if world > 1 else "none",
@@ -689,8 +804,10 @@ def main():
                                           "same scene created a second time",
                        "scene_create_warm_ms": wl.scene_create_warm_ms,
                        "wall_clock_per_frame_ms": (wl.scene_create_warm_ms or wl.scene_create_ms) + elapsed / args.steps * 1e3},
+            "step_spread": step_spread(each, float(W) * H * spp),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "exchange": exchange_evidence(rk, lib_collective, collective_note, per_rank),
             "per_rank": per_rank,
             "per_rank_is": "HIP-event time per step inside rptgpu_render_batch_reduce on each rank: its own tiles / the gather "
                            "(includes waiting for the slowest rank) / on rank 0 the assembly of the frame and its D2H",
@@ -704,48 +821,65 @@ def main():
             out["n1_reference"] = committed_n1_line(args.scene, W, H, B, spp)
             if out["n1_reference"]:
                 out["n1_reference"]["speedup_of_this_line"] = out["n1_reference"]["ms_per_step"] / out["ms_per_step"]
-        # ---- the other BASELINE configs on the same clock (1 GPU, default invocation only)
-        if default_run and world == 1 and not args.no_other_configs:
-            others = []
-            for name, ospp in OTHER_CONFIGS:
-                t_cfg = time.perf_counter()
-                try:
-                    o = Workload(name, args, 0, 1, local_rank, backend, spp=ospp, is_headline=False)
-                    buf = np.empty(o.W * o.H * 3, dtype=np.float32)
-                    osteps, owarm = OTHER_STEPS, OTHER_WARMUP
-                    for _ in range(owarm):
-                        o.gpu.render_batch_reduce(o.camera, o.params(), root=0, out=buf)
-                        o.step_no += 1
-                    torch.cuda.synchronize()
-                    o.gpu.reset_stats()
-                    t1 = time.perf_counter()
-                    for _ in range(osteps):
-                        o.gpu.render_batch_reduce(o.camera, o.params(), root=0, out=buf)
-                        o.step_no += 1
-                    torch.cuda.synchronize()
-                    dt = time.perf_counter() - t1
-                    ost = o.gpu.stats()
+    gpu.close()  # (idempotent: at N = 1 with live counters it was closed before the child ran)
+
+    # ---- the other BASELINE configs on the same clock.  N = 1: all four, with counters and CPU baselines.  N > 1: the two
+    # that BASELINE assigns to 8 GPUs, through the same sharded path and exchange as the headline
+    if default_run and not args.no_other_configs:
+        others = []
+        if world == 1:
+            cfgs, osteps, owarm = OTHER_CONFIGS, OTHER_STEPS, OTHER_WARMUP
+        else:
+            cfgs, osteps, owarm = MULTI_GPU_OTHER_CONFIGS, MULTI_GPU_OTHER_STEPS, MULTI_GPU_OTHER_WARMUP
+        for name, ospp in cfgs:
+            t_cfg = time.perf_counter()
+            entry = None
+            try:
+                o = Workload(name, args, rank, world, local_rank, backend, spp=ospp, is_headline=False)
+                ostep, olib, onote_x, _ = setup_exchange(rk, o)
+                dt, oeach, ost, oper_rank = timed_steps(rk, o, ostep, osteps, owarm)
+                if rank == 0:
                     ob, oosc = accounting(o, ost)
                     ok, odom, okn = kernel_table(o, ost, ob)
-                    o.gpu.close()
-                    opmc, onote = (None, "--no-live-pmc") if args.no_live_pmc else live_pmc(name, ospp, (PMC_A,))
-                    oroof = roofline_object(o, ost, ok, odom, okn, ob, opmc, onote, ospp)
+                o.gpu.close()
+                if rank == 0:
+                    opmc, onote = (None, "--no-live-pmc" if world == 1 else "live counters are collected at N=1 only") \
+                        if (args.no_live_pmc or world > 1) else live_pmc(name, min(ospp, PMC_MAX_SPP), (PMC_A,))
+                    oroof = roofline_object(o, ost, ok, odom, okn, ob, opmc, onote, min(ospp, PMC_MAX_SPP))
                     oroof["kernels"] = {k: {"launches": v["launches"], "avg_ms": v["avg_ms"], "total_ms": v["total_ms"]} for k, v in ok.items()}
-                    ocpu = None if args.no_cpu_baseline else cpu_baseline(o, None, 4.0, args.cpu_spp)
-                    others.append({"workload": "%s %dx%d, %d bounces, %d spp per step" % (name, o.W, o.H, o.B, ospp),
-                                   "value": float(o.W) * o.H * ospp * osteps / dt / 1e6, "unit": "Msamples/s",
-                                   "ms_per_step": dt / osteps * 1e3, "steps": osteps, "warmup": owarm, "spp": ospp,
-                                   "scene_create_ms": o.scene_create_ms,
-                                   "rays_per_s": (ost.extend_rays + ost.shadow_rays_traced) / dt,
-                                   "reference_rays_per_s": (ost.extend_rays + ost.shadow_rays) / dt,
-                                   "roofline": oroof, "cpu_baseline": ocpu,
-                                   "wall_s_of_this_entry": None})
-                except Exception as e:  # one config must not cost the bench line
-                    others.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
-                others[-1]["wall_s_of_this_entry"] = time.perf_counter() - t_cfg
+                    ocpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(o, None, 4.0, args.cpu_spp)
+                    rays_t = float(sum(r["extend_rays"] + r["shadow_rays_traced"] for r in oper_rank))
+                    rays_r = float(sum(r["extend_rays"] + r["shadow_rays"] for r in oper_rank))
+                    entry = {"workload": "%s %dx%d, %d bounces, %d spp per step" % (name, o.W, o.H, o.B, ospp),
+                             "value": float(o.W) * o.H * ospp * osteps / dt / 1e6, "unit": "Msamples/s", "n_gpus": world,
+                             "ms_per_step": dt / osteps * 1e3, "steps": osteps, "warmup": owarm, "spp": ospp,
+                             "step_spread": step_spread(oeach, float(o.W) * o.H * ospp),
+                             "scene_create_ms": o.scene_create_ms,
+                             "rays_per_s": rays_t / dt, "reference_rays_per_s": rays_r / dt,
+                             "roofline": oroof, "cpu_baseline": ocpu,
+                             "wall_s_of_this_entry": None}
+                    if world > 1:
+                        rms = [r["render_ms_per_step"] for r in oper_rank]
+                        entry["rank_render_ms"] = {"max": max(rms), "min": min(rms)}
+                        entry["exchange"] = exchange_evidence(rk, olib, onote_x, oper_rank)
+                        entry["n1_reference"] = committed_n1_line(name, o.W, o.H, o.B, ospp)
+            except Exception as e:  # one config must not cost the bench line
+                if world > 1:
+                    raise  # (with several ranks a failure on one of them cannot be skipped over: the others would wait)
+                entry = {"workload": name, "error": "%s: %s" % (type(e).__name__, e)}
+            if rank == 0:
+                entry["wall_s_of_this_entry"] = time.perf_counter() - t_cfg
+                others.append(entry)
+        if rank == 0:
             out["other_configs"] = others
+            for e in others:  # one top-level scalar per config, so that a reader who keeps only scalars keeps them
+                key = SCALAR_KEYS.get(str(e.get("workload", "")).split(" ")[0])
+                if key and "value" in e:
+                    out[key] = e["value"]
+                    out[key + "_spp_per_step"] = e["spp"]
+    if rank == 0:
         print(json.dumps(out))
-    gpu.close()
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

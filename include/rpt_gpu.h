@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPTGPU_ABI_VERSION 6
+#define RPTGPU_ABI_VERSION 7
 
 /* ---- error codes (replace the reference's panics: buffer.rs:26,33,89, plane.rs:35) ---- */
 enum {
@@ -302,13 +302,19 @@ typedef struct RptSceneOptions {
   int32_t env_park;               /* RPTGPU_ENV_PARK (1): rpt_paths parks the texture lookups of escaped rays per lane and runs
                                      them for the wave together; 0 = each on the spot                                       */
   uint32_t paths_batch;           /* RPTGPU_PATHS_BATCH (0 = per launch: 1/32 of a wave's share of the launch's work items, within
-                                     [16, 256]): work items a wave of rpt_paths claims with one atomic on the work counter   */
+                                     [16, 256]; at most 1024): work items a wave of rpt_paths claims with one atomic on the
+                                     work counter                                                                            */
 } RptSceneOptions;
+/* Fills *out (sizeof(RptSceneOptions) of THIS header, 112 bytes) with the defaults. */
 void rptgpu_scene_options_default(RptSceneOptions* out);
-/* opts == NULL: the defaults.  opts->struct_size must be sizeof(RptSceneOptions) of this ABI version (or smaller, of an
- * older one: missing fields take their defaults); RPTGPU_E_INVALID_ARGUMENT otherwise. */
+/* ABI v7 — the same for a caller whose header may be older: writes exactly struct_size bytes.  struct_size must be a size
+ * the struct has had (104: the first v6 header, before env_park; 112); RPTGPU_E_INVALID_ARGUMENT otherwise. */
+int rptgpu_scene_options_default_sized(RptSceneOptions* out, uint32_t struct_size);
+/* opts == NULL: the defaults.  opts->struct_size must be one of those sizes (the fields a smaller struct lacks take their
+ * defaults); RPTGPU_E_INVALID_ARGUMENT otherwise, also when a field — or an RPTGPU_* override of one — is out of range. */
 int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOptions* opts, rptgpu_scene** out);
-/* the options a handle runs with, environment overrides applied */
+/* The options a handle runs with, environment overrides applied.  ABI v7: the caller sets out->struct_size to the size of
+ * ITS struct before the call (rptgpu_scene_options_default[_sized] leaves it set); exactly that many bytes are written. */
 int rptgpu_scene_get_options(const rptgpu_scene* h, RptSceneOptions* out);
 
 /* ---- the hot path: replaces the body of Renderer::sample (renderer.rs:117-129).
@@ -349,7 +355,10 @@ int rptgpu_render_batch_device(rptgpu_scene* h, const RptCamera* camera,
  * memory), sees an asynchronous RCCL error or times out aborts its communicator (ncclCommAbort) and
  * returns RPTGPU_E_COMM / its own error; its peers then run into their time-out or an RCCL error and do
  * the same.  After that every further rptgpu_render_batch_reduce on the handle returns RPTGPU_E_COMM until
- * rptgpu_comm_destroy + rptgpu_comm_init.  Argument errors that every rank makes alike (bad params) are
+ * rptgpu_comm_destroy + rptgpu_comm_init.  The library's stream is drained before the error is returned (nothing is
+ * written into out_rgb32 afterwards); should the device not finish within the time-out again, the handle is ABANDONED
+ * (ABI v7): its workspace may still be in use by that work, so every later call that would enqueue work on it returns
+ * RPTGPU_E_COMM — destroy it.  Argument errors that every rank makes alike (bad params) are
  * returned before anything is enqueued and leave the communicator alone. */
 #define RPTGPU_UNIQUE_ID_BYTES 128
 int rptgpu_comm_unique_id(uint8_t out_id[RPTGPU_UNIQUE_ID_BYTES]);

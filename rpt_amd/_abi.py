@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPTGPU_LIB") or os.path.join(HERE, "lib", "librptgpu.so")  # RPTGPU_LIB: dev A/B builds
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 RPTGPU_OK = 0
 RPTGPU_E_INVALID_ARGUMENT = -1
@@ -102,7 +102,7 @@ RPT_COLLECTIVE_DEFAULT, RPT_COLLECTIVE_GATHER, RPT_COLLECTIVE_REDUCE = 0, 1, 2
 
 
 class RptSceneOptions(C.Structure):
-    """include/rpt_gpu.h RptSceneOptions (ABI v6): the knobs of a scene handle; rptgpu_scene_options_default fills it."""
+    """include/rpt_gpu.h RptSceneOptions (ABI v6, sized access v7): the knobs of a scene handle; rptgpu_scene_options_default fills it."""
     _fields_ = [("struct_size", C.c_uint32), ("_reserved0", C.c_uint32),
                 ("deep_depth", C.c_uint32), ("fast_max_depth", C.c_uint32),
                 ("sort_rays", C.c_int32), ("rays_in_kernel", C.c_int32),
@@ -142,6 +142,7 @@ SYMBOLS = [
     ("rptgpu_scene_create", C.c_int, [C.POINTER(RptScene), C.c_int, C.POINTER(_VP)]),
     ("rptgpu_scene_destroy", None, [_VP]),
     ("rptgpu_scene_options_default", None, [C.POINTER(RptSceneOptions)]),
+    ("rptgpu_scene_options_default_sized", C.c_int, [C.POINTER(RptSceneOptions), C.c_uint32]),
     ("rptgpu_scene_create_opts", C.c_int, [C.POINTER(RptScene), C.c_int, C.POINTER(RptSceneOptions), C.POINTER(_VP)]),
     ("rptgpu_scene_get_options", C.c_int, [_VP, C.POINTER(RptSceneOptions)]),
     ("rptgpu_render_batch", C.c_int, [_VP, C.POINTER(RptCamera), C.POINTER(RptRenderParams), _PD]),

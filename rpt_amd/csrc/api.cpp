@@ -224,6 +224,8 @@ struct rptgpu_scene {
   std::vector<uint64_t> gather_off;        // [world + 1] offsets (pixels) into gather_pixels
   uint32_t gather_key[5] = {0, 0, 0, 0, 0}; // width, height, world, root, 1
   bool comm_failed = false;                // a batch's collective failed: sticky until comm_destroy + comm_init
+  bool abandoned = false;                  // an aborted batch's work did not drain: kernels of it may still run on the old stream
+                                           // and touch the workspace — nothing more is enqueued on this handle, ever
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
   ~rptgpu_scene() {
@@ -504,10 +506,21 @@ const char* bad_params(const RptRenderParams* p) {
   return nullptr;
 }
 
+// A handle whose aborted batch never drained (rptgpu_render_batch_reduce, drain_after_abort): the abandoned stream's
+// kernels may still read and write the workspace, the frame buffers and events, so every call that would enqueue work
+// refuses — until rptgpu_scene_destroy.
+#define REFUSE_IF_ABANDONED(h)                                                                                            \
+  do {                                                                                                                    \
+    if ((h) && (h)->abandoned)                                                                                            \
+      return fail((h), RPTGPU_E_COMM, "an aborted batch's device work never drained on this handle: destroy it (its "    \
+                                      "workspace may still be written by the abandoned stream)");                        \
+  } while (0)
+
 // packed (with d_out, f32 or f64): d_out receives only this part's pixels, [npix][3] in the order of the part's pixel list
 int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* p, void* d_out, bool out_f32,
                 double* host_out, hipStream_t user_stream, bool packed = false) {
   if (!h || !camera || !p) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  REFUSE_IF_ABANDONED(h);
   if (const char* why = bad_params(p)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, why);
   auto t0 = std::chrono::steady_clock::now();
   try {
@@ -567,7 +580,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       uint64_t n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk);
       // 32-bit work counter: every lane of the grid may ask once past the end, and a wave's last guided claim may reach
       // past it (kernels/paths.inc fetch_item: at most 64 + 256 dead items per wave), so items + 8 x threads must fit
-      const uint64_t item_limit = 0xFFFFFFF0ull - (uint64_t)h->num_cus * 16 * 512;
+      // (slack: at most RPT_PATHS_WAVES_PER_CU_MAX one-wave blocks per CU — checked below — each with up to 64 askers past
+      // the end and one last claim of at most RPT_PATHS_BATCH_MAX, the cap of a caller's paths_batch)
+      const uint64_t item_limit = 0xFFFFFFF0ull - (uint64_t)h->num_cus * RPT_PATHS_WAVES_PER_CU_MAX * (64u + RPT_PATHS_BATCH_MAX);
       if (n_items > item_limit) {
         chunk = (uint32_t)(((uint64_t)spp_l * npix + item_limit - 1) / item_limit);
         while ((n_items = (uint64_t)npix * ((spp_l + chunk - 1) / chunk)) > item_limit) chunk++;
@@ -575,7 +590,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       const bool flat = h->all_flat && !h->dscene.force_general;
       FlatLayout lay = flat ? h->flat_layout : FlatLayout{};
       const uint32_t flat_lds = lay.off_end;
-      int per_cu = kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds, false);
+      int per_cu = std::min(kt->paths_max_blocks_per_cu(flat ? &lay : nullptr, flat_lds, false), (int)RPT_PATHS_WAVES_PER_CU_MAX);
       // a texture environment: the lanes park their lookups in what the wave's LDS share has left (kernels/paths.inc) —
       // unless that costs a resident wave (a flat scene that fills the share)
       bool park = flat && h->opt.env_park != 0 && h->dscene.env_kind != RPT_ENV_COLOR; // (flat scenes: rpt_paths<KdLds>'s stack fills the share)
@@ -808,8 +823,12 @@ int rptgpu_device_count(int* out_count) {
   return RPTGPU_OK;
 }
 
-void rptgpu_scene_options_default(RptSceneOptions* o) {
-  if (!o) return;
+namespace {
+// the sizes RptSceneOptions has had under this ABI's headers: the first v6 header (before env_park / paths_batch) and today's
+constexpr uint32_t OPT_SIZE_V6_FIRST = 104u, OPT_SIZE_NOW = (uint32_t)sizeof(RptSceneOptions);
+static_assert(sizeof(RptSceneOptions) == 112, "a grown RptSceneOptions is a new known size: add it to known_opt_size");
+bool known_opt_size(uint32_t n) { return n == OPT_SIZE_V6_FIRST || n == OPT_SIZE_NOW; }
+void options_default_full(RptSceneOptions* o) {
   std::memset(o, 0, sizeof *o);
   o->struct_size = (uint32_t)sizeof *o;
   o->deep_depth = 8;              // a tree this deep pays for compaction + its own launches
@@ -831,17 +850,45 @@ void rptgpu_scene_options_default(RptSceneOptions* o) {
   o->comm_timeout_s = 300.0;
   o->env_park = 1;
 }
+// the caller's struct may be the smaller one of an older header: never write past ITS size
+void copy_options_out(const RptSceneOptions& full, RptSceneOptions* out, uint32_t out_size) {
+  std::memcpy(out, &full, out_size);
+  out->struct_size = out_size;
+}
+const char* options_out_of_range(const RptSceneOptions& opt) {
+  if (opt.sort_rays < -1 || opt.sort_rays > 1 || opt.deep_depth < 1u || opt.lbuf_bytes < 24u ||
+      opt.workspace_bytes < (1ull << 20) || !(opt.comm_timeout_s > 0.0) || (opt.target_paths && opt.target_paths < 1024u) ||
+      opt.paths_batch > RPT_PATHS_BATCH_MAX)
+    return "RptSceneOptions: a field is out of range";
+  return nullptr;
+}
+} // namespace
+
+void rptgpu_scene_options_default(RptSceneOptions* o) {
+  if (!o) return;
+  options_default_full(o); // (this header's struct: the full size)
+}
+
+int rptgpu_scene_options_default_sized(RptSceneOptions* o, uint32_t struct_size) {
+  if (!o) return RPTGPU_E_INVALID_ARGUMENT;
+  if (!known_opt_size(struct_size))
+    return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "rptgpu_scene_options_default_sized: struct_size is not a size RptSceneOptions has had under this ABI (104, 112)");
+  RptSceneOptions full;
+  options_default_full(&full);
+  copy_options_out(full, o, struct_size);
+  return RPTGPU_OK;
+}
 
 namespace {
 // the environment's overrides of the options (the variables' names: include/rpt_gpu.h, RptSceneOptions), read HERE and
 // nowhere else: once per handle, while it is made
-void apply_env_overrides(RptSceneOptions& o) {
+void apply_env_overrides(RptSceneOptions& o, bool user_set_build_min) {
   auto ll = [](const char* name, long long& v) { if (const char* e = std::getenv(name)) { v = std::atoll(e); return true; } return false; };
   long long v;
   // several ranks on one node share the host's cores (host_scene.cpp usable_cpus): the device build pays earlier
   for (const char* name : {"RPTGPU_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
     if (const char* e = std::getenv(name)) {
-      if (std::atoi(e) > 1 && o.device_build_min == 32768) o.device_build_min = 4096;
+      if (std::atoi(e) > 1 && !user_set_build_min) o.device_build_min = 4096; // (a default only: a caller's own 32768 stands)
       break;
     }
   if (ll("RPTGPU_DEVICE_BUILD_MIN", v)) o.device_build_min = (uint64_t)std::max(0ll, v);
@@ -849,7 +896,7 @@ void apply_env_overrides(RptSceneOptions& o) {
   if (ll("RPTGPU_FAST_MAX_DEPTH", v)) o.fast_max_depth = (uint32_t)std::max(0ll, v);
   if (ll("RPTGPU_DEEP_DEPTH", v)) o.deep_depth = (uint32_t)std::max(1ll, v);
   if (ll("RPTGPU_RAYS_IN_KERNEL", v)) o.rays_in_kernel = v != 0 ? 1 : 0;
-  if (ll("RPTGPU_SORT_RAYS", v)) o.sort_rays = v != 0 ? 1 : 0;
+  if (ll("RPTGPU_SORT_RAYS", v)) o.sort_rays = v < 0 ? -1 : (v != 0 ? 1 : 0); // (-1, the documented default: by the tree's footprint)
   if (ll("RPTGPU_SORT_MIN_BYTES", v)) o.sort_min_bytes = (uint64_t)std::max(0ll, v);
   if (ll("RPTGPU_SORT_SHADOW_MIN_BYTES", v)) o.sort_shadow_min_bytes = (uint64_t)std::max(0ll, v);
   if (ll("RPTGPU_SORT_MIN_RAYS", v)) o.sort_min_rays = (uint32_t)std::max(0ll, std::min(v, 0xffffffffll));
@@ -858,7 +905,7 @@ void apply_env_overrides(RptSceneOptions& o) {
   if (ll("RPTGPU_OBJECT_FILTER_MIN", v)) o.object_filter_min = (int32_t)v;
   if (ll("RPTGPU_PATHS_CHUNK", v)) o.paths_chunk = (uint32_t)std::max(0ll, v);
   if (ll("RPTGPU_ENV_PARK", v)) o.env_park = v != 0 ? 1 : 0;
-  if (ll("RPTGPU_PATHS_BATCH", v)) o.paths_batch = (uint32_t)std::max(0ll, std::min(v, 65536ll));
+  if (ll("RPTGPU_PATHS_BATCH", v)) o.paths_batch = (uint32_t)std::max(0ll, std::min(v, (long long)RPT_PATHS_BATCH_MAX));
   if (ll("RPTGPU_LBUF_BYTES", v) && v >= 24) o.lbuf_bytes = (uint64_t)v;
   if (const char* e = std::getenv("RPTGPU_TARGET_PATHS")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= 1024) o.target_paths = u; }
   if (const char* e = std::getenv("RPTGPU_WS_BYTES")) { uint64_t u = std::strtoull(e, nullptr, 10); if (u >= (1ull << 20)) o.workspace_bytes = u; }
@@ -868,7 +915,11 @@ void apply_env_overrides(RptSceneOptions& o) {
 
 int rptgpu_scene_get_options(const rptgpu_scene* h, RptSceneOptions* out) {
   if (!h || !out) return RPTGPU_E_INVALID_ARGUMENT;
-  *out = h->opt;
+  // the CALLER says how large its struct is (out->struct_size, set before the call — rptgpu_scene_options_default[_sized]
+  // does): a caller built against the 104-byte first v6 header gets 104 bytes, not an overrun of eight
+  if (!known_opt_size(out->struct_size))
+    return fail(const_cast<rptgpu_scene*>(h), RPTGPU_E_INVALID_ARGUMENT, "rptgpu_scene_get_options: set out->struct_size to sizeof(RptSceneOptions) of your header first (rptgpu_scene_options_default does)");
+  copy_options_out(h->opt, out, out->struct_size);
   return RPTGPU_OK;
 }
 
@@ -880,18 +931,19 @@ int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOp
   if (!scene || !out) return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
   RptSceneOptions opt;
-  rptgpu_scene_options_default(&opt);
-  if (user_opts) { // a caller built against an older (smaller) struct: the fields it does not know keep their defaults
-    if (user_opts->struct_size < 8u || user_opts->struct_size > sizeof opt)
+  options_default_full(&opt);
+  bool user_set_build_min = false;
+  if (user_opts) { // a caller built against the older (smaller) struct: the fields it does not know keep their defaults
+    if (!known_opt_size(user_opts->struct_size)) // (only whole structs: a size in between would cut a field in half)
       return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "RptSceneOptions::struct_size does not belong to this ABI version (use rptgpu_scene_options_default)");
     std::memcpy(&opt, user_opts, user_opts->struct_size);
     opt.struct_size = (uint32_t)sizeof opt;
-    if (opt.sort_rays < -1 || opt.sort_rays > 1 || opt.deep_depth < 1u || opt.lbuf_bytes < 24u ||
-        opt.workspace_bytes < (1ull << 20) || !(opt.comm_timeout_s > 0.0) || (opt.target_paths && opt.target_paths < 1024u) ||
-        opt.paths_batch > 65536u)
-      return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, "RptSceneOptions: a field is out of range");
+    if (const char* why = options_out_of_range(opt)) return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, why);
+    user_set_build_min = true;
   }
-  apply_env_overrides(opt);
+  apply_env_overrides(opt, user_set_build_min);
+  if (const char* why = options_out_of_range(opt)) // the overrides are held to the same ranges as the fields
+    return fail(nullptr, RPTGPU_E_INVALID_ARGUMENT, std::string(why) + " (after the RPTGPU_* environment overrides)");
   opt.fast_max_depth = std::min(opt.fast_max_depth, (uint32_t)rptdev::KD_MAX_STACK);
   rpthost::FlatScene fs;
   std::string err;
@@ -1206,6 +1258,7 @@ int rptgpu_comm_init(rptgpu_scene* h, int rank, int world, const uint8_t id[RPTG
   Rccl& r = rccl();
   if (!r.ok) return fail(h, RPTGPU_E_COMM, r.why);
   if (h->comm) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "the handle already has a communicator");
+  REFUSE_IF_ABANDONED(h);
   h->comm_failed = false;
   if (hipSetDevice(h->device) != hipSuccess) return fail(h, RPTGPU_E_HIP, "hipSetDevice");
   RcclUniqueId uid;
@@ -1252,6 +1305,7 @@ void ensure_gather_lists(rptgpu_scene* h, uint32_t width, uint32_t height, uint3
 int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, int root,
                                float* out_rgb32) {
   if (!h || !camera || !params) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  REFUSE_IF_ABANDONED(h);
   if (h->comm_failed)
     return fail(h, RPTGPU_E_COMM, "an earlier batch's collective failed on this handle: rptgpu_comm_destroy + rptgpu_comm_init before the next one");
   const int world = h->comm ? h->comm_world : 1, rank = h->comm ? h->comm_rank : 0;
@@ -1292,10 +1346,11 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
       if (std::chrono::steady_clock::now() > deadline) break;
       if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
-    hipStream_t fresh = nullptr;
-    if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) h->stream = fresh; // (the old stream is not destroyed: that would block on it)
-    else (void)hipGetLastError();
-    note = " — the library's stream did not drain after the abort: out_rgb32 may be written to until the device finishes";
+    // The handle is finished: the old stream's kernels may still touch its workspace, frame buffers and events, so a
+    // later render on a fresh stream would race with them.  Every call that enqueues work refuses from now on
+    // (REFUSE_IF_ABANDONED); rptgpu_scene_destroy frees the memory (hipFree waits for the device).
+    h->abandoned = true;
+    note = " — the library's stream did not drain after the abort: out_rgb32 may be written to until the device finishes, and this handle accepts no further work (destroy it)";
   };
   if (rank == root && !out_rgb32) return fail_comm(RPTGPU_E_INVALID_ARGUMENT, "null out_rgb32 on the root rank");
   // waits for the library's stream; with a communicator it polls the stream together with RCCL's asynchronous error
@@ -1433,6 +1488,7 @@ int rptgpu_render_batch_reduce(rptgpu_scene* h, const RptCamera* camera, const R
 int rptgpu_render_batch_emulate_ranks(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams* params, int world,
                                       float* out_rgb32) {
   if (!h || !camera || !params || !out_rgb32) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
+  REFUSE_IF_ABANDONED(h);
   if (world < 1 || world > 4096) return fail(h, RPTGPU_E_INVALID_ARGUMENT, "world out of range");
   if (const char* why = bad_params(params)) return fail(h, RPTGPU_E_INVALID_ARGUMENT, why);
   const uint64_t n = (uint64_t)params->width * params->height * 3;
@@ -1474,6 +1530,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
   if (!h || (n && (!origins || !dirs || !out_t || !out_normal || !out_object)))
     return fail(h, RPTGPU_E_INVALID_ARGUMENT, "null argument");
   if (precision_mode != RPT_PRECISION_F64_STRICT) return fail(h, RPTGPU_E_INVALID_ARGUMENT, BAD_MODE);
+  REFUSE_IF_ABANDONED(h);
   if (!n) return RPTGPU_OK;
   try {
     HIP_TRY(hipSetDevice(h->device));

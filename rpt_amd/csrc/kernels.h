@@ -23,6 +23,11 @@ static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * m
 #define RPT_PARK_K 4
 #endif
 #define RPT_PATHS_PARK_LDS (RPT_PARK_K * 2624u)
+// rpt_paths's 32-bit work counter: a wave's last claim may overshoot the end by its batch (kernels/paths.inc fetch_item), so
+// a caller's RptSceneOptions::paths_batch is capped, and api.cpp leaves WAVES_PER_CU_MAX x (64 + BATCH_MAX) items of room
+// per CU (one-wave blocks: the occupancy query's answer is clamped to the same bound)
+#define RPT_PATHS_BATCH_MAX 1024u
+#define RPT_PATHS_WAVES_PER_CU_MAX 32u
 
 // layout of the flat path kernel's dynamic LDS (byte offsets; lrec at 0), see kernels.inc
 struct FlatLayout {

@@ -61,6 +61,7 @@ class GpuScene:
     def options(self):
         """The options the handle runs with (defaults, the caller's, environment overrides) as a dict."""
         o = _abi.RptSceneOptions()
+        o.struct_size = C.sizeof(_abi.RptSceneOptions)  # ABI v7: the caller says how large ITS struct is
         _abi.check(self.lib.rptgpu_scene_get_options(self.handle, C.byref(o)), self.handle)
         return {name: getattr(o, name) for name, _ in _abi.RptSceneOptions._fields_ if not name.startswith("_")}
 

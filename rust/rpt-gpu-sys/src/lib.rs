@@ -21,7 +21,7 @@ use std::sync::Arc;
 pub mod ffi {
     use std::os::raw::{c_char, c_int, c_void};
 
-    pub const RPTGPU_ABI_VERSION: c_int = 6;
+    pub const RPTGPU_ABI_VERSION: c_int = 7;
     pub const RPTGPU_OK: c_int = 0;
     pub const RPTGPU_E_INVALID_ARGUMENT: c_int = -1;
     pub const RPTGPU_E_UNSUPPORTED_SHAPE: c_int = -2;
@@ -257,6 +257,7 @@ pub mod ffi {
         pub fn rptgpu_scene_create(scene: *const RptScene, device: c_int, out: *mut *mut rptgpu_scene) -> c_int;
         pub fn rptgpu_scene_destroy(h: *mut rptgpu_scene);
         pub fn rptgpu_scene_options_default(out: *mut RptSceneOptions);
+        pub fn rptgpu_scene_options_default_sized(out: *mut RptSceneOptions, struct_size: u32) -> c_int;
         pub fn rptgpu_scene_create_opts(scene: *const RptScene, device: c_int, opts: *const RptSceneOptions, out: *mut *mut rptgpu_scene) -> c_int;
         pub fn rptgpu_scene_get_options(h: *const rptgpu_scene, out: *mut RptSceneOptions) -> c_int;
         pub fn rptgpu_render_batch(h: *mut rptgpu_scene, camera: *const RptCamera, params: *const RptRenderParams, out_rgb: *mut f64) -> c_int;
@@ -450,10 +451,11 @@ impl GpuScene {
     /// The back-end's knobs with the library's defaults (`rptgpu_scene_options_default`): change fields, then
     /// `GpuScene::with_options`.  None of them changes a result.
     pub fn default_options() -> RptSceneOptions {
-        let mut o = std::mem::MaybeUninit::<RptSceneOptions>::uninit();
-        // SAFETY: the library writes every field of the struct it is given
+        let mut o = std::mem::MaybeUninit::<RptSceneOptions>::zeroed();
+        // SAFETY: the library writes exactly the size it is told (ABI v7), i.e. THIS crate's struct even when the
+        // library's own has grown since; an all-zero RptSceneOptions is a valid value should the size be unknown to it
         unsafe {
-            ffi::rptgpu_scene_options_default(o.as_mut_ptr());
+            let _ = ffi::rptgpu_scene_options_default_sized(o.as_mut_ptr(), std::mem::size_of::<RptSceneOptions>() as u32);
             o.assume_init()
         }
     }
@@ -471,7 +473,7 @@ impl GpuScene {
     /// The options the handle runs with: defaults, the caller's, `RPTGPU_*` environment overrides.
     pub fn options(&self) -> Result<RptSceneOptions, GpuError> {
         let mut o = Self::default_options();
-        // SAFETY: a live handle and a struct of the library's own size
+        // SAFETY: a live handle; `o.struct_size` (set by default_options) tells the library how many bytes it may write
         check(unsafe { ffi::rptgpu_scene_get_options(self.h, &mut o) }, self.h)?;
         Ok(o)
     }

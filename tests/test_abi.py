@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == {s[0] for s in _abi.SYMBOLS}
-    assert lib.rptgpu_abi_version() == _abi.ABI_VERSION == 6
+    assert lib.rptgpu_abi_version() == _abi.ABI_VERSION == 7
 
 
 def test_struct_sizes_match_header(tmp_path):
@@ -47,7 +47,7 @@ def test_struct_sizes_match_header(tmp_path):
 
 
 def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch):
-    """RptSceneOptions (ABI v6): the library fills the defaults, rejects a struct of a size it does not know and fields out
+    """RptSceneOptions (ABI v6 / v7): the library fills the defaults, rejects a struct of a size it does not know and fields out
     of range BEFORE anything else is looked at (no GPU needed), and takes a smaller struct of an older header."""
     lib = _abi.load_library()
     o = _abi.RptSceneOptions()
@@ -71,18 +71,48 @@ def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch
     bad.struct_size = C.sizeof(_abi.RptSceneOptions) + 8
     assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT and b"struct_size" in lib.rptgpu_last_error_detail(None)
     for field, value in (("sort_rays", 2), ("deep_depth", 0), ("lbuf_bytes", 8), ("workspace_bytes", 1000),
-                         ("comm_timeout_s", 0.0), ("target_paths", 5), ("paths_batch", 1 << 20)):
+                         ("comm_timeout_s", 0.0), ("target_paths", 5), ("paths_batch", 1025)):
         bad = rpt_amd.device.scene_options(**{field: value})
         assert create(bad) == _abi.RPTGPU_E_INVALID_ARGUMENT, field
-    old = rpt_amd.device.scene_options(sort_rays=0)
-    old.struct_size = 24  # a caller that knows the first four fields only: the rest keep their defaults
-    assert create(old) == _abi.RPTGPU_E_NO_DEVICE
+    for cut in (8, 24, 100, 108):  # only WHOLE structs of a header that existed: a size in between cuts a field in half
+        old = rpt_amd.device.scene_options(sort_rays=0)
+        old.struct_size = cut
+        assert create(old) == _abi.RPTGPU_E_INVALID_ARGUMENT, cut
     old = rpt_amd.device.scene_options(paths_chunk=4)
     old.struct_size = 104  # the first v6 header, before env_park
     assert create(old) == _abi.RPTGPU_E_NO_DEVICE
     with pytest.raises(TypeError):
         rpt_amd.device.scene_options(no_such_field=1)
     assert lib.rptgpu_scene_get_options(None, C.byref(o)) == _abi.RPTGPU_E_INVALID_ARGUMENT
+    # the environment's overrides are held to the fields' ranges too; RPTGPU_SORT_RAYS=-1 IS the documented default
+    monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "3")
+    monkeypatch.setenv("RPTGPU_SORT_RAYS", "-1")
+    assert create(None) == _abi.RPTGPU_E_NO_DEVICE
+    monkeypatch.setenv("RPTGPU_LBUF_BYTES", "24")
+    monkeypatch.setenv("RPTGPU_COMM_TIMEOUT_S", "-5")  # (ignored: not a positive number)
+    assert create(None) == _abi.RPTGPU_E_NO_DEVICE
+
+
+def test_sized_option_access_never_writes_past_the_callers_struct():
+    """a caller built against the 104-byte first v6 header must not get 112 bytes written into its
+    struct.  rptgpu_scene_options_default_sized writes exactly the size it is told and knows only the sizes the struct
+    has had; (rptgpu_scene_get_options does the same with out->struct_size — needs a handle: tests/test_gpu_parity.py)."""
+    lib = _abi.load_library()
+    full = C.sizeof(_abi.RptSceneOptions)
+    assert full == 112
+    for size in (104, 112):
+        raw = (C.c_uint8 * (full + 16))(*([0xAB] * (full + 16)))
+        o = C.cast(raw, C.POINTER(_abi.RptSceneOptions))
+        assert lib.rptgpu_scene_options_default_sized(o, size) == _abi.RPTGPU_OK
+        assert o.contents.struct_size == size and o.contents.deep_depth == 8 and o.contents.comm_timeout_s == 300.0
+        assert all(b == 0xAB for b in raw[size:]), size  # nothing behind the caller's struct was touched
+        if size == 112:
+            assert o.contents.env_park == 1 and o.contents.paths_batch == 0
+    for size in (0, 8, 100, 108, 120):
+        raw = (C.c_uint8 * (full + 16))(*([0xAB] * (full + 16)))
+        assert lib.rptgpu_scene_options_default_sized(C.cast(raw, C.POINTER(_abi.RptSceneOptions)), size) == _abi.RPTGPU_E_INVALID_ARGUMENT
+        assert all(b == 0xAB for b in raw)
+    assert lib.rptgpu_scene_options_default_sized(None, 112) == _abi.RPTGPU_E_INVALID_ARGUMENT
 
 
 def test_strerror_and_kernel_names():

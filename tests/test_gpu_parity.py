@@ -611,15 +611,19 @@ def test_bench_two_ranks_equal_one_rank(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-frame", one] + common,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    env = dict(os.environ, RPT_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--dump-frame", two] + common, capture_output=True, text=True, env=env)
+    # NO launcher: `python bench.py --gpus 2` starts its own two ranks (the driver's form of the call)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["RPT_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dump-frame", two] + common,
+                       capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert "bench.py itself" in out["config"]["launched_by"]
+    assert out["exchange"]["ranks"] == 2 and out["exchange"]["library_exchange_ran"] is False  # gloo stand-in: said so
     # the N > 1 line reads on its own: the ranks' render times as max / min, and the committed 1-GPU line of the same
     # workload when there is one (none for this test's frame size)
     assert out["rank_render_ms"]["max"] >= out["rank_render_ms"]["min"] >= 0 and len(out["per_rank"]) == 2  # (0 under the gloo stand-in: the library's own exchange did not run)
