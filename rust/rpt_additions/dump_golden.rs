@@ -2,7 +2,8 @@
 //!
 //!     cargo run --release --features philox --example dump_golden -- out_dir
 //!
-//! Renders small versions of examples/sphere.rs and examples/cornell.rs on the CPU with the Philox stream
+//! Renders small versions of examples/sphere.rs and examples/cornell.rs — and, when `examples/teapot.obj` is where the
+//! crate keeps it, a scene around that mesh (kd-tree build + traversal, metal, glass, delta lights) — on the CPU with the Philox stream
 //! (seed, pixel, sample) and writes the W*H*3 f64 means (little endian, row-major, top row first — the `colors`
 //! vector of Renderer::sample, renderer.rs:118-127) to `<out_dir>/<name>.f64` plus a `<name>.txt` with the
 //! parameters.  `python scripts/compare_rust_golden.py out_dir` in the back-end repository renders the same
@@ -78,4 +79,25 @@ fn main() {
     ));
     let camera = Camera { eye: glm::vec3(278.0, 273.0, -800.0), direction: glm::vec3(0.0, 0.0, 1.0), up: glm::vec3(0.0, 1.0, 0.0), fov: 0.686, aperture: 0.0, focal_distance: 0.0 };
     dump(&dir, "cornell", &scene, camera, 64, 36, 8, 8, 102);
+
+    // examples/teapot.rs's mesh and placement (KdTree::new + intersect_subtree on the crate's own 2 256-face asset), with a
+    // glass sphere beside it (the transparent branches of bsdf / sample_f), six bounces; run from the crate's root
+    if let Ok(file) = fs::File::open("examples/teapot.obj") {
+        let mut scene = Scene::new();
+        scene.add(
+            Object::new(load_obj(file).unwrap().scale(&glm::vec3(0.5, 0.5, 0.5)).translate(&glm::vec3(0.0, -1.0, 0.0)))
+                .material(Material::metallic(hex_color(0xff0000), 0.4)),
+        );
+        scene.add(
+            Object::new(sphere().scale(&glm::vec3(0.4, 0.4, 0.4)).translate(&glm::vec3(1.3, -0.6, 0.8)))
+                .material(Material::clear(1.5, 0.02)),
+        );
+        scene.add(Object::new(plane(glm::vec3(0.0, 1.0, 0.0), -1.0)).material(Material::diffuse(hex_color(0xaaaaaa))));
+        scene.add(Light::Ambient(glm::vec3(0.02, 0.02, 0.02)));
+        scene.add(Light::Point(glm::vec3(60.0, 60.0, 60.0), glm::vec3(0.0, 5.0, 5.0)));
+        scene.environment = Environment::Color(glm::vec3(0.3, 0.4, 0.6));
+        dump(&dir, "teapot", &scene, Camera::default(), 64, 64, 6, 8, 103);
+    } else {
+        println!("teapot: examples/teapot.obj not found (run from the crate's root): skipped");
+    }
 }

@@ -106,3 +106,43 @@ def test_scene_with_a_device_built_tree_renders_the_same_frame(monkeypatch):
     img = g.render_batch(cam, p)
     g.close()
     assert (img == ref).all() and np.isfinite(img).all() and img.max() > 0
+
+
+def oracle_tree(oracle, boxes):
+    """KdTree::new as oracle/oracle.cpp restates it line by line (kdtree.rs:108-119, 235-355: three full stable sorts per node)"""
+    return kdtree_build(boxes, oracle.lib(), "oracle")
+
+
+@pytest.mark.parametrize("n,seed", [(16, 3), (200, 5), (5000, 6), (40000, 7)])
+def test_random_boxes_device_equals_the_oracles_construct(oracle, n, seed):
+    """The DIRECT comparison (not through the host builder): the tree the device builds is the tree the oracle's
+    `construct` builds — node for node, leaf entry for leaf entry, split bits included."""
+    rs = np.random.RandomState(seed)
+    lo = rs.rand(n, 3) * 10
+    boxes = np.concatenate([lo, lo + rs.rand(n, 3) * (0.1 + 2.0 * (seed % 2))], axis=1)
+    d, o = kdtree_build(boxes, device=0), oracle_tree(oracle, boxes)
+    for k in ("split", "info", "a", "b", "refs"):
+        assert d[k].shape == o[k].shape and (d[k] == o[k]).all(), k
+    assert d["max_depth"] == o["max_depth"]
+    assert (d["split"].view(np.uint64) == o["split"].view(np.uint64)).all()
+
+
+@pytest.mark.parametrize("order,negative", MIXED_ZERO_ORDERS)
+def test_zero_median_device_equals_the_oracles_construct(oracle, order, negative):
+    boxes = mixed_zero_boxes(order)
+    d, o = kdtree_build(boxes, device=0), oracle_tree(oracle, boxes)
+    for k in ("split", "info", "a", "b", "refs"):
+        assert (d[k] == o[k]).all(), k
+    assert (d["split"].view(np.uint64) == o["split"].view(np.uint64)).all()
+
+
+def test_full_size_meshes_device_equals_the_oracles_construct(oracle):
+    """The trees the BASELINE mesh configs actually render with (C3: 100 352 triangles; C5: the lathed glass), built on
+    the device, against the oracle's construct."""
+    for rows in (scenes.knot_mesh(), scenes.lathe_glass_mesh()):
+        boxes = tri_boxes(rows)
+        d, o = kdtree_build(boxes, device=0), oracle_tree(oracle, boxes)
+        for k in ("split", "info", "a", "b", "refs"):
+            assert d[k].shape == o[k].shape and (d[k] == o[k]).all(), k
+        assert d["max_depth"] == o["max_depth"] >= 12
+        assert (d["split"].view(np.uint64) == o["split"].view(np.uint64)).all()
