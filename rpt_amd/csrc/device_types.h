@@ -1,5 +1,5 @@
 // device_types.h — the flattened, device-resident scene and the wavefront path state.
-// Shared by the host flattener / API (host_scene.cpp, api.cpp) and the gfx950 kernels.
+// Shared by the host flattener / API (host_scene.cpp, api_*.cpp) and the gfx950 kernels.
 //
 // Layout rules (MI355X): everything a lane gathers on its own (kd nodes, triangles, group
 // children) is a 16-byte-aligned record so one `global_load_dwordx4` (or a run of them) fetches
@@ -95,11 +95,11 @@ struct alignas(16) Tree {
   uint64_t sample_zone; // rand 0.8 UniformInt zone for Uniform::from(0..num_prims): u64::MAX - (2^64 - n) % n,
                         // precomputed because a 64-bit modulo costs ~200 device instructions per light sample
   uint32_t mesh_kids;   // GROUP: some child is a MESH (a kd-tree of kd-trees): such an object is walked by the per-tree
-                        // kernels whatever its own depth (api.cpp)
+                        // kernels whatever its own depth (api_scene.cpp)
   uint32_t generic_only; // the tree of a top-level object that only rpt_tree_generic walks (a group among a group's
                         // children, mesh children rpt_nest_trace does not take): rpt_tree_enter hands it every ray.
                         // (A tree deeper than KD_MAX_STACK is NOT one: rpt_tree_trace takes it, with the levels
-                        // beyond its LDS stack in the spill columns, which api.cpp sizes from the deepest tree.)
+                        // beyond its LDS stack in the spill columns, which api_render.cpp sizes from the deepest tree.)
   double qlo[3];        // MESH: origin and step of the LeafBox fixed-point grid (coordinate = qlo + q * qscale)
   double qscale[3];
 };

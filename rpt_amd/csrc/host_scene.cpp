@@ -54,7 +54,7 @@ int usable_cpus() {
 // fn(begin, end) over [0, n) in contiguous pieces on the usable CPUs; small ranges, or a box that cannot start threads,
 // run on the caller's.  For the per-triangle / per-leaf-entry loops of the flattening (independent items).
 // Host threads of the flattening and the kd build: RptSceneOptions::build_threads while a scene is being made
-// (flatten_scene sets it for its thread; the environment's override is already folded in, api.cpp), else — the
+// (flatten_scene sets it for its thread; the environment's override is already folded in, api_scene.cpp), else — the
 // handle-less rptgpu_kdtree_build — RPTGPU_BUILD_THREADS; 0 = the usable cores.
 thread_local int t_build_threads = 0;
 int forced_build_threads() {
@@ -521,7 +521,7 @@ struct Flattener {
     }
     if (on_device) fs.trees_built_on_device++;
     else kd_build(boxes, kb);
-    // (a tree deeper than KD_MAX_STACK is no error: the object it belongs to is walked by rpt_tree_generic, api.cpp)
+    // (a tree deeper than KD_MAX_STACK is no error: the object it belongs to is walked by rpt_tree_generic, api_scene.cpp)
     fs.max_tree_depth = std::max(fs.max_tree_depth, kb.max_depth);
     rptdev::Tree t;
     std::memset(&t, 0, sizeof(t));

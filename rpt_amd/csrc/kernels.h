@@ -5,7 +5,7 @@
 
 #include "device_types.h"
 
-// meshes per batched run of the flat path kernel (kernels/paths.inc flat_query; api.cpp caps Inst::plane_use with it)
+// meshes per batched run of the flat path kernel (kernels/paths.inc flat_query; api_scene.cpp caps Inst::plane_use with it)
 #ifndef RPT_FLAT_RUN
 #define RPT_FLAT_RUN 6
 #endif
@@ -24,7 +24,7 @@ static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * m
 #endif
 #define RPT_PATHS_PARK_LDS (RPT_PARK_K * 2624u)
 // rpt_paths's 32-bit work counter: a wave's last claim may overshoot the end by its batch (kernels/paths.inc fetch_item), so
-// a caller's RptSceneOptions::paths_batch is capped, and api.cpp leaves WAVES_PER_CU_MAX x (64 + BATCH_MAX) items of room
+// a caller's RptSceneOptions::paths_batch is capped, and api_render.cpp leaves WAVES_PER_CU_MAX x (64 + BATCH_MAX) items of room
 // per CU (one-wave blocks: the occupancy query's answer is clamped to the same bound)
 #define RPT_PATHS_BATCH_MAX 1024u
 #define RPT_PATHS_WAVES_PER_CU_MAX 32u
@@ -66,7 +66,7 @@ struct SortBufs {
 #endif
 #define RPT_TT_LEVELS_MIN RPT_TT_LEVELS
 // spill area of the traversal stack beyond the LDS levels: [KD_MAX_STACK - RPT_TT_LEVELS_MIN][threads] per array, one
-// column per thread of the traversal grid (api.cpp allocates it for scenes with deep trees)
+// column per thread of the traversal grid (api_render.cpp allocates it for scenes with deep trees)
 // rpt_tree_generic's pending work (kernels/wavefront.inc), one column per thread of ITS grid: deferred far children
 // (six face parameters, t_split, node) and the suspended leaves of the groups above the tree being walked
 struct GenericStack {
@@ -85,7 +85,7 @@ struct StackSpill {
   // reads that row (and the slot from the query's queue) instead of gathering eight values from the path state's SoA
   // arrays.  The tree's queues hold positions, not slots.
   double* rays;
-  // rpt_tree_generic: its columns, the flag it raises if a scene outgrows them (api.cpp sizes them from the scene and
+  // rpt_tree_generic: its columns, the flag it raises if a scene outgrows them (api_render.cpp sizes them from the scene and
   // checks the flag when the batch is done), and its grid when it takes a few handed-on rays / every ray of an object
   GenericStack gen;
   uint32_t* gen_overflow;

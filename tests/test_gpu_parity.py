@@ -420,7 +420,7 @@ def test_groups_with_tree_children_take_the_per_tree_pipeline_whatever_is_asked(
 def test_trees_deeper_than_the_fast_stacks(name, monkeypatch, oracle):
     """A tree deeper than the in-kernel traversals' private stacks (KD_MAX_STACK = 32) is sent through the per-tree
     kernels, whose stack beyond the LDS levels is a global column as high as the scene's deepest tree, and a nested tree
-    that deep through rpt_tree_generic.  The reference's build rule keeps real trees far below 32 (api.cpp says why), so
+    that deep through rpt_tree_generic.  The reference's build rule keeps real trees far below 32 (api_scene.cpp says why), so
     the threshold is lowered here (RPTGPU_FAST_MAX_DEPTH): every mesh of these fixtures is then "too deep"."""
     monkeypatch.setenv("RPTGPU_FAST_MAX_DEPTH", "3")
     scene, cam, p = small_scenes.small(name)

@@ -1,7 +1,7 @@
 """The work-item hand-out of rpt_paths (kernels/paths.inc fetch_item: a wave-level pool refilled by ONE atomic on the global
 counter, batches sized by the host and guided towards the end) restated in Python and run as a discrete simulation: whatever
 the interleaving of the waves' requests, every item is handed to exactly one lane, a lane is told "no item" only after the
-counter has passed the end, and the counter never exceeds what api.cpp leaves room for below 2^32 (items + 8 x threads).
+counter has passed the end, and the counter never exceeds what api_render.cpp leaves room for below 2^32 (items + 8 x threads).
 The device code is tested through its results (tests/test_gpu_parity.py::test_work_item_pools_are_scheduling_only); this
 pins the arithmetic the comment in paths.inc argues about."""
 import random
@@ -74,7 +74,7 @@ def test_every_item_goes_to_exactly_one_lane(n_items, nblocks, option):
     # dead items: every lane asks at most once past the end, plus the wave's last guided claim
     assert max(w.dead for w in waves) <= 64
     assert counter[0] <= n_items + nblocks * (64 + batch)
-    assert counter[0] <= n_items + 8 * nthreads  # api.cpp's item_limit leaves 8 x the grid's threads (>= this grid's)
+    assert counter[0] <= n_items + 8 * nthreads  # api_render.cpp's item_limit leaves 8 x the grid's threads (>= this grid's)
 
 
 def test_batches_shrink_towards_the_end():
