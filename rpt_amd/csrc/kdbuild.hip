@@ -514,6 +514,9 @@ bool kd_build_device(const std::vector<Box>& boxes, KdBuild& out, int device, st
   bool ok = false;
   int prev_device = -1; // the caller's current device is put back: a library call must not move it
   (void)hipGetDevice(&prev_device);
+  // hipGetLastError() reports the thread's LAST failed runtime call, whoever made it: rocPRIM checks it after its launches
+  // and would hand an old failure (another call's bad device ordinal, say) back as its own.  Start from a clean slate.
+  (void)hipGetLastError();
   try {
     KD_TRY(hipSetDevice(device));
     KD_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

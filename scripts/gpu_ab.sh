@@ -13,7 +13,7 @@ for sc in $2; do
     v=${vv%%@*}; E=""; if [ "$vv" != "$v" ]; then E=$(echo "${vv#*@}" | tr ',' ' '); fi
     if [ "$v" = base ]; then L=$PWD/rpt_amd/lib/librptgpu.so; else L=$PWD/rpt_amd/lib/librptgpu_$v.so; fi
     v=$(echo "$vv" | tr '@=,' '___')
-    env $E RPTGPU_LIB=$L timeout 300 python bench.py --scene $scene --steps 2 --warmup 1 --spp $spp --no-cpu-baseline --no-live-pmc 2>$O/err_${scene}_$v.txt | python -c "
+    env $E RPTGPU_LIB=$L timeout ${RUN_TIMEOUT:-300} python bench.py --scene $scene --steps 2 --warmup 1 --spp $spp --no-cpu-baseline --no-live-pmc 2>$O/err_${scene}_$v.txt | python -c "
 import sys,json
 try:
     d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels']

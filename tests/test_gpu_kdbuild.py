@@ -146,3 +146,15 @@ def test_full_size_meshes_device_equals_the_oracles_construct(oracle):
             assert d[k].shape == o[k].shape and (d[k] == o[k]).all(), k
         assert d["max_depth"] == o["max_depth"] >= 12
         assert (d["split"].view(np.uint64) == o["split"].view(np.uint64)).all()
+
+
+def test_a_failed_call_elsewhere_does_not_poison_the_device_build():
+    """hipGetLastError() is per thread and sticky: a runtime call that failed earlier (here: a build asked for on a device
+    that does not exist) used to come back as rocPRIM's own error from the NEXT device build ("invalid device ordinal" out
+    of radix_sort_pairs).  kd_build_device starts from a clean slate."""
+    rs = np.random.RandomState(11)
+    lo = rs.rand(300, 3)
+    boxes = np.concatenate([lo, lo + 0.05], axis=1)
+    with pytest.raises(_abi.RptGpuError):
+        kdtree_build(boxes, device=99)
+    assert_same_tree(kdtree_build(boxes, device=0), kdtree_build(boxes))
