@@ -277,7 +277,11 @@ def committed_n1_line(scene, W, H, B, spp):
     for path in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")) + glob.glob(os.path.join(ROOT, "profiles", "r*_%s_bench_line.json" % scene)):
         m = re.match(r"r(\d+)_", os.path.basename(path))
         try:
-            d = json.loads(open(path).read().strip().splitlines()[-1])
+            text = open(path).read().strip()
+            try:
+                d = json.loads(text)  # (an indented dump: profiles/rNN_<scene>_bench_line.json)
+            except ValueError:
+                d = json.loads(text.splitlines()[-1])  # (the bench's own single line after other output)
         except Exception:
             continue
         if not m or d.get("n_gpus") != 1 or not str((d.get("config") or {}).get("workload", "")).startswith(want):

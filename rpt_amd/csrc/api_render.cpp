@@ -352,6 +352,17 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
                     (uint32_t)((uint64_t)npix * ((spp + chunk - 1) / chunk)), nblocks, lay, flat, flat_lds, park, h->opt.paths_batch);
           b.done(); }
         kt->sum_samples(st, fr, h->lbuf.p, spp, s0 == 0);
+        if (std::getenv("RPTGPU_PRINT_LAUNCH")) { // diagnostics: where the 32-bit work counter ended (kernels/paths.inc fetch_item)
+          uint32_t ended = 0;
+          HIP_TRY(hipMemcpyAsync(&ended, h->counters.p, sizeof ended, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+          const uint64_t items = (uint64_t)npix * ((spp + chunk - 1) / chunk);
+          const uint32_t batch_used = h->opt.paths_batch ? std::min<uint32_t>(h->opt.paths_batch, RPT_PATHS_BATCH_MAX)
+                                                          : std::min(256u, std::max((uint32_t)items / (std::max(1u, nblocks) * 32u), 16u));
+          std::fprintf(stderr, "rpt_paths work counter: ended at %u for %llu items; %u waves, claims of at most %u: dead claims %lld of at most %llu\n",
+                       ended, (unsigned long long)items, nblocks, batch_used, (long long)ended - (long long)items,
+                       (unsigned long long)nblocks * (64u + batch_used));
+        }
       }
       HIP_TRY(hipGetLastError());
       kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32, packed);

@@ -7,14 +7,16 @@
 #   4. per-phase lane-occupancy tables from the -DRPT_PROF build (rpt_amd/lib/librptgpu_prof.so, if present)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 O=gpurun_out/${TAG}final; mkdir -p $O
 export TMPDIR=/tmp
 export RPT_PROFILE_DST=$REPO/$O/profiles
 mkdir -p $RPT_PROFILE_DST
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
-LIST=${1:-"cornell:0:512 dragon:32:16 wine_glass:8:4 fractal_spheres:8:4 room23:64:64 glass:64:64"}
+# (trace spp of the two configs BASELINE assigns to 8 GPUs = 64: their <scene>_bench_line.json is the 1-GPU line of the same
+# workload that an N > 1 bench line carries along as n1_reference)
+LIST=${1:-"cornell:0:512 dragon:32:16 wine_glass:64:4 fractal_spheres:64:4 room23:64:64 glass:64:64"}
 for item in $LIST; do
   IFS=: read sc tspp pspp <<< "$item"
   bash scripts/profile.sh $TAG $sc $tspp $pspp "--no-live-pmc" > $O/profile_$sc.log 2>&1
@@ -29,6 +31,11 @@ if [ -f $P ]; then
     RPTGPU_LIB=$P RPTGPU_PRINT_PHASES=1 timeout 300 python bench.py --scene $1 --steps 1 --warmup 0 --spp $2 $3 $4 --no-cpu-baseline --no-live-pmc 2>&1 >/dev/null | grep "^prof" >> $O/phase_tables.txt
   done
 fi
+# 5. the full-size parity sweep on THIS build (two seeds, 1/8 of the tiles each), headed by the commit it ran on
+( echo "# scripts/parity_sweep.py on commit ${COMMIT:-unknown} (the tree gpurun sent), $(date -u +%Y-%m-%dT%H:%MZ)"
+  timeout 1500 python scripts/parity_sweep.py 16 8 3 0xABCDE
+  timeout 1500 python scripts/parity_sweep.py 16 8 6 0x5EED5 ) > $O/parity_sweep.txt 2>&1
+tail -2 $O/parity_sweep.txt
 timeout 300 python bench.py --scene simple_video > $O/simple_video.json 2>/dev/null
 timeout 300 python bench.py --scene fractal_teapots --bounces 8 --spp 64 --steps 2 --warmup 1 --no-live-pmc > $O/fractal_teapots_b8.json 2>/dev/null
 TAG=$TAG python - <<'PY'

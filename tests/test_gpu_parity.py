@@ -311,6 +311,30 @@ def test_work_item_pools_are_scheduling_only(name, batch):
     g.close()
 
 
+@pytest.mark.parametrize("batch", [0, 1, 7, 256, 1024])
+def test_work_counter_ends_within_the_bound_the_host_leaves_room_for(batch, monkeypatch, capfd):
+    """The KERNEL's own bookkeeping, not a model of it: rpt_paths's 32-bit work counter after a launch, read back
+    by the library (RPTGPU_PRINT_LAUNCH).  Every item is claimed (counter >= items) and the claims past the end stay within
+    waves x (64 askers + one last claim of at most the batch) — what api_render.cpp's item_limit leaves room for below
+    2^32; the image being the fixture's says every item was rendered exactly once."""
+    import re
+    monkeypatch.setenv("RPTGPU_PRINT_LAUNCH", "1")
+    scene, cam, p = small_scenes.small("cornell")
+    g = GpuScene(scene, 0, paths_batch=batch)
+    capfd.readouterr()
+    img = g.render_batch(cam, make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed,
+                                          flags=_abi.RPT_FLAG_PERSISTENT))
+    err = capfd.readouterr().err
+    g.close()
+    assert (img == load("cornell")["image"]).all()
+    found = re.findall(r"work counter: ended at (\d+) for (\d+) items; (\d+) waves, claims of at most (\d+): dead claims (-?\d+) of at most (\d+)", err)
+    assert found, err[-500:]
+    for ended, items, waves, claim, dead, bound in (tuple(int(x) for x in f) for f in found):
+        assert ended >= items and dead == ended - items
+        assert claim == (batch if batch else claim) and claim <= 1024
+        assert 0 <= dead <= bound == waves * (64 + claim), (ended, items, waves, claim)
+
+
 def _hdri_scene(kind):
     """glass.rs's pair of spheres, a ring of seven glass / metal / diffuse spheres (the object filter of flat scenes), a
     glass cube on a polygon with a lamp (a flat scene with its triangles in LDS) — each under a synthetic HDRI"""
