@@ -24,6 +24,7 @@ for item in $LIST; do
   rm -rf gpurun_out/prof_${TAG}_$sc
 done
 P=$PWD/rpt_amd/lib/librptgpu_prof.so
+rm -f $O/phase_tables.txt
 if [ -f $P ]; then
   for sc in "cornell 64" "room23 32" "glass 16" "dragon 16" "wine_glass 4" "fractal_spheres 4" "fractal_teapots 16 --bounces 8"; do
     set -- $sc
