@@ -293,9 +293,10 @@ typedef struct RptSceneOptions {
   uint32_t paths_chunk;           /* RPTGPU_PATHS_CHUNK (0 = per launch: 16, 2 for filtered flat scenes at 4+ bounces, fewer
                                      when a lane would get under 24 items): samples per work item of the persistent path kernel       */
   /* memory */
-  uint64_t workspace_bytes;       /* RPTGPU_WS_BYTES (96 GiB): cap of the wavefront pipeline's path state                 */
+  uint64_t workspace_bytes;       /* RPTGPU_WS_BYTES (240 GiB; and never more than 85 % of the free memory): cap of the
+                                     wavefront pipeline's path state                                                          */
   uint64_t lbuf_bytes;            /* RPTGPU_LBUF_BYTES (32 GiB): cap of the per-sample radiance buffer of rpt_paths        */
-  uint64_t target_paths;          /* RPTGPU_TARGET_PATHS (0 = what the workspace cap holds, at most 128 Mi): paths per pass */
+  uint64_t target_paths;          /* RPTGPU_TARGET_PATHS (0 = what the workspace cap holds, at most 512 Mi): paths per pass */
   /* multi-GPU */
   double comm_timeout_s;          /* RPTGPU_COMM_TIMEOUT_S (300): a batch's exchange is given up after this long           */
   /* routing, added after the first v6 header (struct_size 104): a caller built against that one gets the default */

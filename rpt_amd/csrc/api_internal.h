@@ -129,6 +129,7 @@ struct rptgpu_scene {
   DevBuf<uint32_t> draw, queue_a, queue_b, counters, pixels;
   DevBuf<uint8_t> nrec;
   uint64_t ws_cap = 0;
+  uint64_t ws_fail_paths = 0;          // the smallest pass (paths) whose workspace did not fit on this device so far; 0 = none
   uint32_t ws_bounces = 0;
   DevBuf<double> prec;                 // persistent kernel: depth records [threads][bounces][8]
   DevBuf<double> lbuf;                 // persistent kernel: radiance of every sample of a launch [spp][3][npix]
@@ -187,7 +188,7 @@ struct rptgpu_scene {
   int ev_used = 0;
   uint64_t target_paths = 0;       // RPTGPU_TARGET_PATHS: paths in flight per pass of the wavefront pipeline; 0 = as many as
                                    // the workspace budget holds (ws_budget_bytes and half of the free HBM), at most 128 Mi
-  uint64_t ws_budget_bytes = 96ull << 30; // RPTGPU_WS_BYTES
+  uint64_t ws_budget_bytes = 240ull << 30; // RPTGPU_WS_BYTES
   // multi-GPU: the communicator of this handle (rptgpu_comm_init) and its frame buffers
   RcclComm comm = nullptr;
   int comm_rank = 0, comm_world = 1;

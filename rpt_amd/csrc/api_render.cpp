@@ -388,11 +388,25 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
           uint64_t have = h->ws_cap * per_path; // what this handle already holds counts as available
-          budget = std::min<uint64_t>(budget, (free_b + have) / 2);
+          // the share of the free memory a pass may take (round 6: 85 %, was 1/2 — the passes of a 288 GB device were sized
+          // for 140 GB; profiles/r06_pass_size_ab.txt).  RPTGPU_WS_FREE_FRACTION (percent): experiments only
+          uint64_t pct = RPT_WS_FREE_PERCENT;
+          if (const char* e = std::getenv("RPTGPU_WS_FREE_FRACTION")) pct = (uint64_t)std::min(95, std::max(5, std::atoi(e)));
+          budget = std::min<uint64_t>(budget, (free_b + have) / 100 * pct);
         }
-        target = std::min<uint64_t>(128ull << 20, std::max<uint64_t>(1ull << 20, budget / per_path));
+        target = std::min<uint64_t>(RPT_MAX_PATHS_PER_PASS, std::max<uint64_t>(1ull << 20, budget / per_path));
       }
+      // a size that did not fit before is not tried again (several handles or processes on one GPU see the same `free`
+      // figure; an explicit target_paths may be more than the device holds): allocating and freeing 100+ GB per call
+      // costs seconds
+      if (h->ws_fail_paths) target = std::min<uint64_t>(target, h->ws_fail_paths / 2);
       uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, target / npix));
+      // passes of EQUAL size: 256 spp with room for 123 per pass are three passes of 86 / 85 / 85, not 123 / 123 / 10 (the
+      // deep bounces of a 10-spp pass run on a tenth of the rays)
+      if (s_chunk < p->iterations) {
+        const uint32_t n_pass = (p->iterations + s_chunk - 1) / s_chunk;
+        s_chunk = (p->iterations + n_pass - 1) / n_pass;
+      }
       // several handles (or processes) on one GPU each see the same `free` figure: if the pass does not fit after
       // all, halve it instead of failing the render (a smaller pass is only slower)
       // (rpt_tree_generic's large grid — whole objects, or under RPT_FLAG_GENERAL_TRAVERSAL everything, go through it: up
@@ -407,6 +421,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           if (e.e != hipErrorOutOfMemory || s_chunk == 1) throw;
           (void)hipGetLastError(); // clear the sticky error before retrying
           release_workspace(h);
+          h->ws_fail_paths = h->ws_fail_paths ? std::min<uint64_t>(h->ws_fail_paths, (uint64_t)npix * s_chunk) : (uint64_t)npix * s_chunk;
           s_chunk = std::max(1u, s_chunk / 2);
         }
       }

@@ -25,7 +25,7 @@ void options_default_full(RptSceneOptions* o) {
   o->device_build_min = 32768;
   o->build_threads = 0;
   o->paths_chunk = 0;
-  o->workspace_bytes = 96ull << 30;
+  o->workspace_bytes = 240ull << 30; // (96 GiB until round 6: a 288 GB device ran passes sized for a third of it)
   o->lbuf_bytes = 32ull << 30;
   o->target_paths = 0;
   o->comm_timeout_s = 300.0;

@@ -26,6 +26,14 @@ static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * m
 // rpt_paths's 32-bit work counter: a wave's last claim may overshoot the end by its batch (kernels/paths.inc fetch_item), so
 // a caller's RptSceneOptions::paths_batch is capped, and api_render.cpp leaves WAVES_PER_CU_MAX x (64 + BATCH_MAX) items of room
 // per CU (one-wave blocks: the occupancy query's answer is clamped to the same bound)
+// the wavefront pipeline's passes: at most this many paths in flight (32-bit slot indices, queue counters and grids have
+// room for 2^31), and at most this share of the device's free memory for their state
+#ifndef RPT_MAX_PATHS_PER_PASS
+#define RPT_MAX_PATHS_PER_PASS (512ull << 20)
+#endif
+#ifndef RPT_WS_FREE_PERCENT
+#define RPT_WS_FREE_PERCENT 85
+#endif
 #define RPT_PATHS_BATCH_MAX 1024u
 #define RPT_PATHS_WAVES_PER_CU_MAX 32u
 

@@ -56,7 +56,7 @@ def test_scene_options_defaults_validation_and_environment_overrides(monkeypatch
     assert (o.deep_depth, o.fast_max_depth, o.sort_rays, o.rays_in_kernel) == (8, 32, -1, 0)
     assert (o.sort_min_bytes, o.sort_shadow_min_bytes, o.sort_min_rays) == (8 << 20, 8 << 20, 1 << 19)
     assert (o.nest_trace, o.leaf_boxes, o.object_filter_min, o.device_build_min) == (1, 1, 5, 32768)
-    assert (o.build_threads, o.paths_chunk, o.workspace_bytes, o.lbuf_bytes, o.target_paths) == (0, 0, 96 << 30, 32 << 30, 0)
+    assert (o.build_threads, o.paths_chunk, o.workspace_bytes, o.lbuf_bytes, o.target_paths) == (0, 0, 240 << 30, 32 << 30, 0)
     assert o.comm_timeout_s == 300.0 and o.env_park == 1 and o.paths_batch == 0
     scene = rpt_amd.Scene()
     scene.add(rpt_amd.Object(rpt_amd.sphere()))

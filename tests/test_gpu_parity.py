@@ -284,7 +284,7 @@ def test_scene_options_route_like_the_environment_did(name, monkeypatch):
     g = GpuScene(scene, 0, deep_depth=1, sort_rays=1, sort_min_rays=0, leaf_boxes=0, paths_chunk=3)
     o = g.options()
     assert (o["deep_depth"], o["sort_rays"], o["sort_min_rays"], o["leaf_boxes"], o["paths_chunk"]) == (1, 1, 0, 0, 3)
-    assert (o["sort_min_bytes"], o["workspace_bytes"]) == (8 << 20, 96 << 30)  # untouched fields: the defaults
+    assert (o["sort_min_bytes"], o["workspace_bytes"]) == (8 << 20, 240 << 30)  # untouched fields: the defaults
     img = g.render_batch(cam, pw)
     g.close()
     assert (img == load(name)["image"]).all()
