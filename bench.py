@@ -19,7 +19,8 @@ through the last bounce, the reduce over ranks, and the write of the W*H mean co
 
 The default 1-GPU run prints ONE JSON line.  Besides the headline it carries
   * `other_configs`: BASELINE configs[2-4] (dragon-class mesh at its 256 spp, fractal spheres, wine glass — mesh and
-    glass-spheres variants) at their own frame sizes and >= 16 spp per step (cost per sample does not depend on spp),
+    glass-spheres variants) at their own frame sizes and 64 spp per step (a step is then a few passes of the size the
+    BASELINE sample counts run in),
     5 steps + 1 warm-up each with median / min / max, each with its own roofline object and CPU baseline (>= 16 spp,
     median of 3 repetitions); their values again as top-level scalars (`c3_msamples`, `c4_msamples`, ...).  At N > 1
     the two configs BASELINE assigns to 8 GPUs (fractal spheres, wine-glass mesh) run through the same sharded path
@@ -54,10 +55,11 @@ ENV = 4 * 32
 FB = 24
 
 # the other BASELINE configs in the default run: (scene, spp per step).  Frame size and bounces are the config's own.
-# (C3 at its BASELINE 256 spp — it fits one GPU; the 4K configs at >= 16 spp; 5 steps + 1 warm-up each, median and
-# min / max on the line; the glass SPHERES variant of C5 — examples/glass.rs — renders 64 spp per step: its step would
-# otherwise be 30 ms)
-OTHER_CONFIGS = (("dragon", 256), ("fractal_spheres", 16), ("wine_glass", 16), ("glass", 64))
+# (C3 at its BASELINE 256 spp — it fits one GPU; the 4K configs at 64 spp per step: BASELINE renders them with 1024 / 4096
+# spp, i.e. in passes as large as the device holds, and since round 6 a pass holds more than 16 spp of a 4K frame — a
+# 16-spp step would time a pass smaller than the config's own (C5 mesh: 913 Msamples/s at 16 spp per step, 964 at 64;
+# profiles/r06_pass_size_ab.txt).  5 steps + 1 warm-up each, median and min / max on the line)
+OTHER_CONFIGS = (("dragon", 256), ("fractal_spheres", 64), ("wine_glass", 64), ("glass", 64))
 OTHER_STEPS, OTHER_WARMUP = 5, 1
 PMC_MAX_SPP = 32  # the counter pass of a secondary config renders at most this many spp (the counters are ratios)
 CPU_MIN_SPP, CPU_REPS = 16, 3
