@@ -24,7 +24,7 @@ The default 1-GPU run prints ONE JSON line.  Besides the headline it carries
     5 steps + 1 warm-up each with median / min / max, each with its own roofline object and CPU baseline (>= 16 spp,
     median of 3 repetitions); their values again as top-level scalars (`c3_msamples`, `c4_msamples`, ...).  At N > 1
     the two configs BASELINE assigns to 8 GPUs (fractal spheres, wine-glass mesh) run through the same sharded path
-    at 64 spp per step, and `exchange` says whether the library's RCCL exchange moved frames in this run;
+    at 256 spp per step, and `exchange` says whether the library's RCCL exchange moved frames in this run;
   * `roofline` objects whose counter fields (VALU busy, lanes active per VALU instruction, HBM bytes, L2 requests)
     are measured IN THIS RUN: bench.py re-runs one step of each workload under `rocprofv3 --pmc ... --kernel-trace`
     in a child process (no torch, ~10 s per pass) and reads the counters back.  If rocprofv3 is not usable the
@@ -648,11 +648,13 @@ def exchange_evidence(rk, lib_collective, note, per_rank):
                      "gloo stand-in (ranks share a device): torch.distributed reduced the frames, the library's RCCL path did not run"))}
 
 
-# the secondary configs an N > 1 run times through the same sharded path: the two BASELINE assigns to 8 GPUs, at >= 64 spp
-# per step (at 16 spp the wavefront pipeline's per-depth fixed costs are x1.6-1.8 of the ideal 1/N per rank,
-# profiles/r05_emulated_ranks.txt)
-MULTI_GPU_OTHER_CONFIGS = (("fractal_spheres", 64), ("wine_glass", 64))
-MULTI_GPU_OTHER_STEPS, MULTI_GPU_OTHER_WARMUP = 3, 1
+# the secondary configs an N > 1 run times through the same sharded path: the two BASELINE assigns to 8 GPUs (1024 / 4096
+# spp there), at 256 spp per step — a rank owns 1/N of the tiles, and its passes should still be as large as the device
+# holds (at 16 spp per step the per-depth fixed costs of a rank's small pass were x1.6-1.8 of the ideal 1/N,
+# profiles/r05_emulated_ranks.txt; pass size against throughput: profiles/r06_pass_size_ab.txt).  The committed 1-GPU lines
+# of the same 256-spp workloads ride along as n1_reference (profiles/r06_<scene>_bench_line.json)
+MULTI_GPU_OTHER_CONFIGS = (("fractal_spheres", 256), ("wine_glass", 256))
+MULTI_GPU_OTHER_STEPS, MULTI_GPU_OTHER_WARMUP = 2, 1
 SCALAR_KEYS = {"dragon": "c3_msamples", "fractal_spheres": "c4_msamples", "wine_glass": "c5_mesh_msamples", "glass": "c5_glass_spheres_msamples"}
 
 

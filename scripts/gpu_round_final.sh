@@ -14,9 +14,9 @@ export RPT_PROFILE_DST=$REPO/$O/profiles
 mkdir -p $RPT_PROFILE_DST
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
-# (trace spp of the two configs BASELINE assigns to 8 GPUs = 64: their <scene>_bench_line.json is the 1-GPU line of the same
+# (trace spp of the two configs BASELINE assigns to 8 GPUs = 256, bench.py's MULTI_GPU_OTHER_CONFIGS: their <scene>_bench_line.json is the 1-GPU line of the same
 # workload that an N > 1 bench line carries along as n1_reference)
-LIST=${1:-"cornell:0:512 dragon:32:16 wine_glass:64:4 fractal_spheres:64:4 room23:64:64 glass:64:64"}
+LIST=${1:-"cornell:0:512 dragon:32:16 wine_glass:256:4 fractal_spheres:256:4 room23:64:64 glass:64:64"}
 for item in $LIST; do
   IFS=: read sc tspp pspp <<< "$item"
   bash scripts/profile.sh $TAG $sc $tspp $pspp "--no-live-pmc" > $O/profile_$sc.log 2>&1
