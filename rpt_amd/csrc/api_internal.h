@@ -129,8 +129,11 @@ struct rptgpu_scene {
   DevBuf<uint32_t> draw, queue_a, queue_b, counters, pixels;
   DevBuf<uint8_t> nrec;
   uint64_t ws_cap = 0;
+  uint64_t ws_rec_cols = 0;            // columns of the depth-record pool (PathState::rec)
+  DevBuf<uint32_t> rec_parent, last_col;
+  double rec_ratio = 0.0;              // record columns a path of this scene needs on average, as measured by the passes so
+  uint32_t rec_ratio_bounces = 0xffffffffu; // far at this max_bounces (0 = not measured yet: the next pass measures)
   uint64_t ws_fail_paths = 0;          // the smallest pass (paths) whose workspace did not fit on this device so far; 0 = none
-  uint32_t ws_bounces = 0;
   DevBuf<double> prec;                 // persistent kernel: depth records [threads][bounces][8]
   DevBuf<double> lbuf;                 // persistent kernel: radiance of every sample of a launch [spp][3][npix]
   uint64_t lbuf_max_bytes = 32ull << 30; // cap on lbuf (RPTGPU_LBUF_BYTES); larger batches run as several launches

@@ -134,18 +134,21 @@ bool generic_overflowed(rptgpu_scene* h, hipStream_t st) {
   return flag != 0;
 }
 
-void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
-  if (cap <= h->ws_cap && max_bounces <= h->ws_bounces && h->ray.p) return;
+// cap: path slots; rec_cols: columns of the depth-record pool (PathState::rec: one per path and depth REACHED)
+void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint64_t rec_cols) {
+  if (cap <= h->ws_cap && rec_cols <= h->ws_rec_cols && h->ray.p) return;
   cap = std::max(cap, h->ws_cap);
-  max_bounces = std::max(max_bounces, h->ws_bounces);
+  rec_cols = std::max(rec_cols, h->ws_rec_cols);
   int nl = std::max(1, h->dscene.num_lights);
   h->ray.alloc(6 * cap);
   h->hit.alloc(4 * cap);
   h->hit_obj.alloc(cap);
   h->draw.alloc(cap);
   h->nrec.alloc(cap);
+  h->last_col.alloc(cap);
   h->rec.release();
-  h->rec.alloc((uint64_t)(max_bounces + 1) * rptdev::REC_FIELDS * cap);
+  h->rec.alloc((uint64_t)rptdev::REC_FIELDS * rec_cols);
+  h->rec_parent.alloc(rec_cols);
   h->shadow.release();
   h->shadow.alloc((uint64_t)nl * rptdev::SHADOW_FIELDS * cap);
   h->queue_a.alloc(cap);
@@ -177,7 +180,7 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint32_t max_bounces) {
     }
   }
   h->ws_cap = cap;
-  h->ws_bounces = max_bounces;
+  h->ws_rec_cols = rec_cols;
 }
 
 // -DRPT_PROF builds (kernels/prof.inc): per phase, the share of the waves' time, the lanes that were active while it
@@ -212,10 +215,11 @@ void print_prof(const KernelTable* kt, const char* what) {
 
 void release_workspace(rptgpu_scene* h) {
   h->ray.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->nrec.release(); h->rec.release();
+  h->rec_parent.release(); h->last_col.release();
   h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
   h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release(); h->tree_rays.release();
   h->gen_defer.release(); h->gen_frame.release(); h->gen_threads = 0; // rpt_tree_generic's columns (ensure_generic makes them again)
-  h->ws_cap = 0; h->ws_bounces = 0;
+  h->ws_cap = 0; h->ws_rec_cols = 0;
 }
 
 rptdev::Camera make_camera(const RptCamera& c) {
@@ -377,87 +381,121 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
     } else if (npix) {
       // Paths in flight per pass.  Late bounces keep few paths alive, and a depth's kernels need ~10^5 rays to fill
       // 256 CUs, so the more paths start together the better the deep bounces run (C3 stand-in: 4 Mi -> 71, 16 Mi ->
-      // 106, 128 Mi -> 128 Msamples/s; 16k-triangle glass 179 -> 324).  288 GB of HBM is what makes that affordable:
-      // a path slot is ~0.8 KB at 8 bounces, so 128 Mi paths are ~100 GB of workspace.
-      uint64_t target = h->target_paths;
-      if (!target) {
-        const uint64_t nl = (uint64_t)std::max(1, h->dscene.num_lights);
-        uint64_t per_path = 6 * 8 + 4 * 8 + 4 + 4 + 1 + (uint64_t)(p->max_bounces + 1) * rptdev::REC_FIELDS * 8 +
-                            nl * rptdev::SHADOW_FIELDS * 8 + 8 + nl * (8 + 4) + (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0);
-        uint64_t budget = h->ws_budget_bytes;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          uint64_t have = h->ws_cap * per_path; // what this handle already holds counts as available
-          // the share of the free memory a pass may take (round 6: 85 %, was 1/2 — the passes of a 288 GB device were sized
-          // for 140 GB; profiles/r06_pass_size_ab.txt).  RPTGPU_WS_FREE_FRACTION (percent): experiments only
-          uint64_t pct = RPT_WS_FREE_PERCENT;
-          if (const char* e = std::getenv("RPTGPU_WS_FREE_FRACTION")) pct = (uint64_t)std::min(95, std::max(5, std::atoi(e)));
-          budget = std::min<uint64_t>(budget, (free_b + have) / 100 * pct);
-        }
-        target = std::min<uint64_t>(RPT_MAX_PATHS_PER_PASS, std::max<uint64_t>(1ull << 20, budget / per_path));
-      }
-      // a size that did not fit before is not tried again (several handles or processes on one GPU see the same `free`
-      // figure; an explicit target_paths may be more than the device holds): allocating and freeing 100+ GB per call
-      // costs seconds
-      if (h->ws_fail_paths) target = std::min<uint64_t>(target, h->ws_fail_paths / 2);
-      uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->iterations, target / npix));
-      // passes of EQUAL size: 256 spp with room for 123 per pass are three passes of 86 / 85 / 85, not 123 / 123 / 10 (the
-      // deep bounces of a 10-spp pass run on a tenth of the rays)
-      if (s_chunk < p->iterations) {
-        const uint32_t n_pass = (p->iterations + s_chunk - 1) / s_chunk;
-        s_chunk = (p->iterations + n_pass - 1) / n_pass;
-      }
-      // several handles (or processes) on one GPU each see the same `free` figure: if the pass does not fit after
-      // all, halve it instead of failing the render (a smaller pass is only slower)
-      // (rpt_tree_generic's large grid — whole objects, or under RPT_FLAG_GENERAL_TRAVERSAL everything, go through it: up
-      // to several hundred MB of columns for a deep mesh — is part of the same attempt: if it does not fit, the pass shrinks)
+      // 106, 128 Mi -> 128 Msamples/s; 16k-triangle glass 179 -> 324; round 6, with passes of 85 % of the free memory:
+      // 786 -> 913, profiles/r06_pass_size_ab.txt).  288 GB of HBM is what makes that affordable.
+      // What a path costs: its slot (ray, hit, queues, per-light shadow state, the per-tree query's row and sort words) and
+      // one 68-byte COLUMN per depth it reaches (PathState::rec) — as many columns as the depths' queues were long, not
+      // (max_bounces + 1) per path: the glass's paths average a quarter of their 17 levels.  How many columns a path needs
+      // is measured (h->rec_ratio: the first pass of a handle is one sample per pixel with the full pool) and carried
+      // with a margin; a pass whose pool runs out at some depth is started over with fewer paths — a pass changes
+      // nothing outside the workspace before its rpt_resolve.
+      const uint64_t nl = (uint64_t)std::max(1, h->dscene.num_lights);
+      const uint64_t per_slot = 6 * 8 + 4 * 8 + 4 + 4 + 1 + 4 + nl * rptdev::SHADOW_FIELDS * 8 + 8 + nl * (8 + 4) +
+                                (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0);
+      const uint64_t per_rec = rptdev::REC_FIELDS * 8 + 4;
+      const double full_ratio = (double)p->max_bounces + 1.0;
+      if (h->rec_ratio_bounces != p->max_bounces) { h->rec_ratio = 0.0; h->rec_ratio_bounces = p->max_bounces; }
       const bool generic_all = h->has_deep && (h->gen_all || h->dscene.force_general);
-      for (;;) {
-        try {
-          ensure_workspace(h, (uint64_t)npix * s_chunk, p->max_bounces);
-          if (generic_all) ensure_generic(h, true);
-          break;
-        } catch (const HipError& e) {
-          if (e.e != hipErrorOutOfMemory || s_chunk == 1) throw;
-          (void)hipGetLastError(); // clear the sticky error before retrying
-          release_workspace(h);
-          h->ws_fail_paths = h->ws_fail_paths ? std::min<uint64_t>(h->ws_fail_paths, (uint64_t)npix * s_chunk) : (uint64_t)npix * s_chunk;
-          s_chunk = std::max(1u, s_chunk / 2);
-        }
-      }
       h->accum.alloc((uint64_t)npix * 3);
       HIP_TRY(hipMemsetAsync(h->accum.p, 0, (uint64_t)npix * 3 * sizeof(double), st));
 
-      rptdev::PathState ps{};
-      ps.ray = h->ray.p; ps.hit = h->hit.p; ps.hit_obj = h->hit_obj.p; ps.draw = h->draw.p;
-      ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.shadow = h->shadow.p; ps.cap = h->ws_cap;
       rptdev::Frame fr{};
       fr.width = p->width; fr.height = p->height; fr.npix = npix; fr.pixels = h->pixels.p;
       fr.max_bounces = p->max_bounces; fr.seed = p->seed; fr.accum = h->accum.p;
       rptdev::Camera cam = make_camera(*camera);
       const bool any_lights = h->dscene.num_lights > 0;
-      // the counter sets the kernels clear for each other start cleared (one memset per render, not one per depth and
-      // per tree and query: 102 of the wine glass's 354 fills per step)
       const uint32_t nctr = 2u + (uint32_t)h->dscene.num_lights;
-      HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * (size_t)nctr * sizeof(uint32_t), st));
-      uint32_t cset = 0;
-      if (h->has_deep) {
-        HIP_TRY(hipMemsetAsync(h->tq_ctr.p, 0, 16 * sizeof(uint32_t), st));
-        h->qtune.ctr_set = 0;
-      }
       QueryMarks qm(h, prof);
       const QueryHook qhook{query_mark, &qm};
 
-      for (uint32_t s0 = 0; s0 < p->iterations; s0 += s_chunk) {
-        uint32_t sc = std::min(s_chunk, p->iterations - s0);
-        uint32_t n_paths = npix * sc;
+      uint32_t s0 = 0;
+      while (s0 < p->iterations) {
+        const uint32_t remaining = p->iterations - s0;
+        // columns per path of this pass: measured + 10 % + 0.05, the full (max_bounces + 1) until there is a measurement
+        // (rounded up to a twentieth, so that the fourth digit of a pass's average does not resize a 100 GB workspace)
+        const double ratio = h->rec_ratio > 0.0 ? std::min(full_ratio, std::ceil((h->rec_ratio * 1.10 + 0.05) * 20.0) / 20.0) : full_ratio;
+        const double per_path = (double)per_slot + ratio * (double)per_rec;
+        uint64_t target = h->target_paths;
+        if (!target) {
+          uint64_t budget = h->ws_budget_bytes;
+          size_t free_b = 0, total_b = 0;
+          if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t have = h->ws_cap * per_slot + h->ws_rec_cols * per_rec; // what this handle already holds counts as available
+            // the share of the free memory a pass may take (round 6: 85 %, was 1/2 — the passes of a 288 GB device were
+            // sized for 140 GB).  RPTGPU_WS_FREE_FRACTION (percent): experiments only
+            uint64_t pct = RPT_WS_FREE_PERCENT;
+            if (const char* e = std::getenv("RPTGPU_WS_FREE_FRACTION")) pct = (uint64_t)std::min(95, std::max(5, std::atoi(e)));
+            budget = std::min<uint64_t>(budget, (free_b + have) / 100 * pct);
+          }
+          target = std::min<uint64_t>(RPT_MAX_PATHS_PER_PASS, std::max<uint64_t>(1ull << 20, (uint64_t)((double)budget / per_path)));
+        }
+        // a size that did not fit before is not tried again (several handles or processes on one GPU see the same `free`
+        // figure; an explicit target_paths may be more than the device holds): allocating and freeing 100+ GB per call
+        // costs seconds
+        if (h->ws_fail_paths) target = std::min<uint64_t>(target, h->ws_fail_paths / 2);
+        uint32_t s_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(remaining, target / npix));
+        if (h->rec_ratio == 0.0 && remaining > 1u && s_chunk > 1u) {
+          s_chunk = 1u; // the measuring pass: one sample per pixel, every path with room for all its levels
+        } else if (s_chunk < remaining) {
+          // passes of EQUAL size: 256 spp with room for 123 per pass are three passes of 86 / 85 / 85, not 123 / 123 / 10
+          // (the deep bounces of a 10-spp pass run on a tenth of the rays)
+          const uint32_t n_pass = (remaining + s_chunk - 1) / s_chunk;
+          s_chunk = (remaining + n_pass - 1) / n_pass;
+        }
+        // several handles (or processes) on one GPU each see the same `free` figure: if the pass does not fit after
+        // all, halve it instead of failing the render (a smaller pass is only slower)
+        // (rpt_tree_generic's large grid — whole objects, or under RPT_FLAG_GENERAL_TRAVERSAL everything, go through it: up
+        // to several hundred MB of columns for a deep mesh — is part of the same attempt: if it does not fit, the pass shrinks)
+        // The workspace is made for the pass a call of this size runs once the measurement is in — not for this pass's
+        // own size: the first call's passes are 1 + (n - 1) samples, and a workspace of n - 1 would be freed and made
+        // again by the second call (220 GB: six seconds)
+        uint32_t s_alloc = s_chunk;
+        if (h->rec_ratio > 0.0) s_alloc = (uint32_t)std::max<uint64_t>(s_chunk, std::min<uint64_t>(p->iterations, target / npix));
+        uint64_t rec_cols = 0;
+        for (;;) {
+          const uint64_t np = (uint64_t)npix * std::max(s_chunk, s_alloc);
+          rec_cols = std::max<uint64_t>(np, std::min<uint64_t>((uint64_t)std::ceil((double)np * ratio), 0xfffffff0ull));
+          try {
+            ensure_workspace(h, np, rec_cols);
+            if (generic_all) ensure_generic(h, true);
+            break;
+          } catch (const HipError& e) {
+            if (e.e != hipErrorOutOfMemory || s_chunk == 1) throw;
+            (void)hipGetLastError(); // clear the sticky error before retrying
+            release_workspace(h);
+            h->ws_fail_paths = h->ws_fail_paths ? std::min<uint64_t>(h->ws_fail_paths, np) : np;
+            if (s_alloc > s_chunk) s_alloc = s_chunk; // (first the room ahead goes, then the pass shrinks)
+            else { s_chunk = std::max(1u, s_chunk / 2); s_alloc = s_chunk; }
+          }
+        }
+        rec_cols = h->ws_rec_cols; // (a workspace kept from an earlier, larger pass: all of its columns)
+
+        rptdev::PathState ps{};
+        ps.ray = h->ray.p; ps.hit = h->hit.p; ps.hit_obj = h->hit_obj.p; ps.draw = h->draw.p;
+        ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
+        ps.shadow = h->shadow.p; ps.cap = h->ws_cap; ps.rec_cap = h->ws_rec_cols;
+        // the counter sets the kernels clear for each other start cleared (one memset per pass, not one per depth and
+        // per tree and query: 102 of the wine glass's 354 fills per step)
+        HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * (size_t)nctr * sizeof(uint32_t), st));
+        uint32_t cset = 0;
+        if (h->has_deep) {
+          HIP_TRY(hipMemsetAsync(h->tq_ctr.p, 0, 16 * sizeof(uint32_t), st));
+          h->qtune.ctr_set = 0;
+        }
+        const RptStats stats_at_start = h->stats; // (a pass that is started over counts once)
+
+        const uint32_t sc = s_chunk;
+        const uint32_t n_paths = npix * sc;
         fr.sample_base = p->sample_index_base + s0;
         { Bracket b(h, RPT_K_RAYGEN, prof); kt->raygen(st, fr, cam, ps, n_paths); b.done(); }
         h->stats.samples += n_paths;
         uint32_t n_active = n_paths;
         const uint32_t* queue = nullptr; // identity at depth 0
         uint32_t* next = h->queue_a.p;
+        uint64_t rec_off = 0; // the depth's first record column
+        bool pool_ran_out = false;
         for (uint32_t depth = 0; depth <= p->max_bounces && n_active; depth++) {
+          if (rec_off + n_active > rec_cols) { pool_ran_out = true; break; }
           // per-tree queries for scenes with deep trees; under RPT_FLAG_GENERAL_TRAVERSAL the whole scene is walked
           // in-kernel in the general form — unless it has a group with tree children, which only the per-tree pipeline
           // walks (there the flag sends every ray of every such object through rpt_tree_generic)
@@ -471,22 +509,22 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
               kt->extend(st, h->dscene, ps, queue, n_active);
             b.done(); }
           h->stats.extend_rays += n_active;
-          const int nl = h->dscene.num_lights;
+          const int nlights = h->dscene.num_lights;
           uint32_t* const ctrs = h->counters.p + (size_t)cset * nctr;       // this depth's counters (cleared by the depth before)
           uint32_t* const ctrs_next = h->counters.p + (size_t)(cset ^ 1u) * nctr;
           cset ^= 1u;
           { Bracket b(h, RPT_K_SHADE, prof);
-            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, ctrs, h->shadow_q.p, ctrs_next, nctr); b.done(); }
+            kt->shade(st, h->dscene, fr, ps, queue, n_active, depth, next, ctrs, h->shadow_q.p, ctrs_next, nctr, (uint32_t)rec_off); b.done(); }
           // The depth's counts come back right after rpt_shade — the one point of a depth where the host waits — so the
           // visibility queries are sized for the shadow rays there ARE (50-70 % of the paths on closed meshes: less to
           // sort, smaller grids, and a light without a single ray at this depth costs no launch at all) and the next
           // depth for its survivors.  Until round 5 the wait stood at the depth's end and the queries ran over the
           // host's bound, the number of paths.  Everything up to the next rpt_shade is then enqueued without a wait.
-          h->cnt_host.resize(2 + (size_t)nl);
+          h->cnt_host.resize(2 + (size_t)nlights);
           uint32_t* cnt = h->cnt_host.data();
-          HIP_TRY(hipMemcpyAsync(cnt, ctrs, (2 + (size_t)nl) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipMemcpyAsync(cnt, ctrs, (2 + (size_t)nlights) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
-          for (int l = 0; l < nl; l++) h->stats.shadow_rays_traced += cnt[2 + l];
+          for (int l = 0; l < nlights; l++) h->stats.shadow_rays_traced += cnt[2 + l];
           if (prof && h->pending.size() >= 256) drain_events(h); // the stream is idle here: cheap
           h->stats.shadow_rays += (uint64_t)cnt[1] * (uint64_t)h->dscene.num_shadow_lights;
           if (any_lights) {
@@ -494,25 +532,42 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
             // device: ctrs + 2 + l is what the kernels read)
             Bracket b(h, RPT_K_SHADOW, prof);
             if (by_object) {
-              for (int l = 0; l < nl; l++)
+              for (int l = 0; l < nlights; l++)
                 if (h->light_casts[l] && cnt[2 + l])
                   kt->query(st, h->dscene, ps, h->shadow_q.p + (uint64_t)l * ps.cap, cnt[2 + l], l, h->srt.p, ctrs + 2 + l, h->obj_deep.data(), h->obj_tris.data(),
                             h->dscene.num_objects, h->tq.p, h->tq_ctr.p, trace_blocks, h->sort_rays ? &h->sort_bufs : nullptr, &qhook, &h->spill, &h->qtune);
             } else { // one launch for all lights of the depth (the grid's y is the light)
               uint32_t n_max = 0;
-              for (int l = 0; l < nl; l++)
+              for (int l = 0; l < nlights; l++)
                 if (h->light_casts[l]) n_max = std::max(n_max, cnt[2 + l]);
-              if (n_max) kt->shadow_rays(st, h->dscene, ps, h->shadow_q.p, ctrs + 2, n_max, nl, h->srt.p);
+              if (n_max) kt->shadow_rays(st, h->dscene, ps, h->shadow_q.p, ctrs + 2, n_max, nlights, h->srt.p);
             }
-            kt->shadow_sum(st, h->dscene, ps, queue, n_active, depth, h->srt.p);
+            kt->shadow_sum(st, h->dscene, ps, queue, n_active, (uint32_t)rec_off, h->srt.p);
             b.done();
           }
+          rec_off += n_active;
           n_active = cnt[0];
           queue = next;
           next = (next == h->queue_a.p) ? h->queue_b.p : h->queue_a.p;
         }
+        if (pool_ran_out) {
+          // more levels per path than the pool was sized for (another camera, a margin too thin): the pass starts over
+          // with room for half as many paths again per column budget; nothing of it has left the workspace
+          HIP_TRY(hipStreamSynchronize(st));
+          h->stats = stats_at_start;
+          const double seen = (double)(rec_off + n_active) / (double)n_paths; // a lower bound of what it needs
+          h->rec_ratio = std::min(full_ratio, std::max(h->rec_ratio, seen) * 1.5);
+          if (std::getenv("RPTGPU_PRINT_LAUNCH"))
+            std::fprintf(stderr, "wavefront pass of %u spp started over: the record pool (%.2f columns per path) ran out; now %.2f\n", sc, ratio, h->rec_ratio);
+          continue;
+        }
         { Bracket b(h, RPT_K_RESOLVE, prof); kt->resolve(st, fr, ps, sc); b.done(); }
         HIP_TRY(hipGetLastError()); // a failed launch is reported here, not by the stream sync
+        h->rec_ratio = std::max(h->rec_ratio, (double)rec_off / (double)n_paths); // columns used per path: the largest average seen
+        if (std::getenv("RPTGPU_PRINT_LAUNCH"))
+          std::fprintf(stderr, "wavefront pass: %u spp, %u paths, %llu record columns used of %llu (%.3f per path, pool sized for %.3f)\n",
+                       sc, n_paths, (unsigned long long)rec_off, (unsigned long long)rec_cols, (double)rec_off / (double)n_paths, ratio);
+        s0 += sc;
       }
       kt->finish(st, fr, (double)p->iterations, std::pow(2.0, p->exposure_value), out, out_f32, packed);
       if (std::getenv("RPTGPU_PRINT_PHASES")) {
@@ -574,10 +629,11 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
       // its own queue, sort and persistent traversal (launch_query) — in pieces of at most 4 Mi rays
       const KernelTable* kt = table_for(precision_mode, h->ext_shapes);
       const uint64_t piece = std::min<uint64_t>(n, 4ull << 20);
-      ensure_workspace(h, piece, 0);
+      ensure_workspace(h, piece, piece);
       rptdev::PathState ps{};
       ps.ray = h->ray.p; ps.hit = h->hit.p; ps.hit_obj = h->hit_obj.p; ps.draw = h->draw.p;
-      ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.shadow = h->shadow.p; ps.cap = h->ws_cap;
+      ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
+      ps.shadow = h->shadow.p; ps.cap = h->ws_cap; ps.rec_cap = h->ws_rec_cols;
       const uint32_t trace_blocks = (uint32_t)std::max(1, h->num_cus * 4);
       std::vector<double> soa(6 * piece), hit(4 * piece);
       for (uint64_t base = 0; base < n; base += piece) {

@@ -151,7 +151,7 @@ struct Camera {
 
 // Per-pass wavefront state, SoA over path slots (slot = s_local * npix + pixel_local).
 // REC_FIELDS doubles per depth record: A[3], f[3], 1/pdf, |wi.n|  (the nested clamp of
-// renderer.rs:162-167 is folded back-to-front by the resolve kernel).
+// renderer.rs:162-167 is folded back-to-front by the resolve kernel, along the records' parent links).
 constexpr int REC_FIELDS = 8;
 constexpr int SHADOW_FIELDS = 7; // wi[3], dist, contribution[3]
 
@@ -161,10 +161,16 @@ struct PathState {
   int32_t* hit_obj;  // [cap]      object index or -1
   uint32_t* draw;    // [cap]      Philox draw counter of the path's stream
   uint8_t* nrec;     // [cap]      number of depth records the path produced (0 = still running)
-  double* rec;       // [max_bounces+1][REC_FIELDS][cap]
+  double* rec;       // [REC_FIELDS][rec_cap]: the pass's depth records, one COLUMN per (path, depth) the path reached — the
+                     // columns of depth d are [rec_off_d, rec_off_d + n_active_d) in the order of that depth's queue (round
+                     // 6; until then [max_bounces + 1][REC_FIELDS][cap]: 1 088 B per path at 16 bounces whatever its length)
+  uint32_t* rec_parent; // [rec_cap] the column of the same path's record one depth up (REC_NONE at depth 0)
+  uint32_t* last_col;   // [cap] the column of the path's deepest record so far
   double* shadow;    // [num_lights][SHADOW_FIELDS][cap]
-  uint64_t cap;      // slots allocated (stride of every array above)
+  uint64_t cap;      // slots allocated (stride of every per-path array above)
+  uint64_t rec_cap;  // columns allocated (stride of rec's fields)
 };
+constexpr uint32_t REC_NONE = 0xffffffffu;
 
 struct Frame {
   uint32_t width, height;

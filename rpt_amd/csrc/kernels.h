@@ -123,7 +123,8 @@ struct KernelTable {
   // counters: [0] paths of the next depth, [1] hits, [2 + l] shadow rays queued for light l; sq: those queues ([light][cap])
   void (*shade)(hipStream_t, const rptdev::Scene&, const rptdev::Frame&, const rptdev::PathState&,
                 const uint32_t* queue, uint32_t n, uint32_t depth, uint32_t* next_queue, uint32_t* counters, uint32_t* sq,
-                uint32_t* zero_next /* rpt_shade clears these zero_n words: the next depth's counters */, uint32_t zero_n);
+                uint32_t* zero_next /* rpt_shade clears these zero_n words: the next depth's counters */, uint32_t zero_n,
+                uint32_t rec_off /* the depth's first record column (PathState::rec) */);
   // visibility of every light of the depth over its shadow-ray queue ([light][cap], lengths sq_counts[light] on the
   // device, the longest at most n_max), whole scene in the kernel (scenes without deep trees): one launch
   void (*shadow_rays)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* sq_all,
@@ -151,7 +152,7 @@ struct KernelTable {
                 const StackSpill* spill /* the traversal stack beyond the LDS levels */, QueryTuning* qt);
   size_t (*sort_temp_bytes)(uint32_t n);
   void (*shadow_sum)(hipStream_t, const rptdev::Scene&, const rptdev::PathState&, const uint32_t* queue, uint32_t n,
-                     uint32_t depth, const double* srt);
+                     uint32_t rec_off, const double* srt);
   // device-resident Buffer (buffer.rs)
   void (*buffer_add)(hipStream_t, double* total, const double* batch, uint64_t n);
   void (*buffer_image)(hipStream_t, const double* total, uint32_t w, uint32_t h, uint32_t radius, uint32_t nb,
