@@ -126,11 +126,12 @@ struct rptgpu_scene {
   // workspace
   DevBuf<double> ray, hit, rec, shadow, accum, out_full;
   DevBuf<int32_t> hit_obj;
-  DevBuf<uint32_t> draw, queue_a, queue_b, counters, pixels;
-  DevBuf<uint8_t> nrec;
+  DevBuf<uint32_t> draw, counters, pixels;
   uint64_t ws_cap = 0;
   uint64_t ws_rec_cols = 0;            // columns of the depth-record pool (PathState::rec)
   DevBuf<uint32_t> rec_parent, last_col;
+  DevBuf<double> ray_next;             // dense path state of the NEXT depth (PathState: rpt_shade writes, the host swaps)
+  DevBuf<uint32_t> draw_next, pid, pid_next, col, col_next;
   double rec_ratio = 0.0;              // record columns a path of this scene needs on average, as measured by the passes so
   uint32_t rec_ratio_bounces = 0xffffffffu; // far at this max_bounces (0 = not measured yet: the next pass measures)
   uint64_t ws_fail_paths = 0;          // the smallest pass (paths) whose workspace did not fit on this device so far; 0 = none

@@ -141,18 +141,18 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint64_t rec_cols) {
   rec_cols = std::max(rec_cols, h->ws_rec_cols);
   int nl = std::max(1, h->dscene.num_lights);
   h->ray.alloc(6 * cap);
+  h->ray_next.alloc(6 * cap);
   h->hit.alloc(4 * cap);
   h->hit_obj.alloc(cap);
-  h->draw.alloc(cap);
-  h->nrec.alloc(cap);
+  h->draw.alloc(cap); h->draw_next.alloc(cap);
+  h->pid.alloc(cap); h->pid_next.alloc(cap);
+  h->col.alloc(cap); h->col_next.alloc(cap);
   h->last_col.alloc(cap);
   h->rec.release();
   h->rec.alloc((uint64_t)rptdev::REC_FIELDS * rec_cols);
   h->rec_parent.alloc(rec_cols);
   h->shadow.release();
   h->shadow.alloc((uint64_t)nl * rptdev::SHADOW_FIELDS * cap);
-  h->queue_a.alloc(cap);
-  h->queue_b.alloc(cap);
   h->counters.alloc(2 * (2 + (size_t)nl)); // two sets (rpt_shade clears the other one) of: [0] next-depth paths, [1] hits, [2 + l] shadow rays queued for light l
   h->shadow_q.release();
   h->shadow_q.alloc((uint64_t)nl * cap); // per light: the paths that cast a shadow ray towards it at the current depth
@@ -214,9 +214,10 @@ void print_prof(const KernelTable* kt, const char* what) {
 }
 
 void release_workspace(rptgpu_scene* h) {
-  h->ray.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->nrec.release(); h->rec.release();
+  h->ray.release(); h->ray_next.release(); h->hit.release(); h->hit_obj.release(); h->draw.release(); h->draw_next.release();
+  h->pid.release(); h->pid_next.release(); h->col.release(); h->col_next.release(); h->rec.release();
   h->rec_parent.release(); h->last_col.release();
-  h->shadow.release(); h->queue_a.release(); h->queue_b.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
+  h->shadow.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
   h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release(); h->tree_rays.release();
   h->gen_defer.release(); h->gen_frame.release(); h->gen_threads = 0; // rpt_tree_generic's columns (ensure_generic makes them again)
   h->ws_cap = 0; h->ws_rec_cols = 0;
@@ -390,7 +391,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       // with a margin; a pass whose pool runs out at some depth is started over with fewer paths — a pass changes
       // nothing outside the workspace before its rpt_resolve.
       const uint64_t nl = (uint64_t)std::max(1, h->dscene.num_lights);
-      const uint64_t per_slot = 6 * 8 + 4 * 8 + 4 + 4 + 1 + 4 + nl * rptdev::SHADOW_FIELDS * 8 + 8 + nl * (8 + 4) +
+      // (ray and next ray, hit, object, draw / path id / parent column twice each, last column, per light the shadow
+      // state, queue entry and record time, the per-tree query's queue, row and sort words)
+      const uint64_t per_slot = 2 * 6 * 8 + 4 * 8 + 4 + 6 * 4 + 4 + nl * rptdev::SHADOW_FIELDS * 8 + nl * (8 + 4) +
                                 (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0);
       const uint64_t per_rec = rptdev::REC_FIELDS * 8 + 4;
       const double full_ratio = (double)p->max_bounces + 1.0;
@@ -472,7 +475,9 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
 
         rptdev::PathState ps{};
         ps.ray = h->ray.p; ps.hit = h->hit.p; ps.hit_obj = h->hit_obj.p; ps.draw = h->draw.p;
-        ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
+        ps.pid = h->pid.p; ps.col = h->col.p;
+        ps.ray_next = h->ray_next.p; ps.draw_next = h->draw_next.p; ps.pid_next = h->pid_next.p; ps.col_next = h->col_next.p;
+        ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
         ps.shadow = h->shadow.p; ps.cap = h->ws_cap; ps.rec_cap = h->ws_rec_cols;
         // the counter sets the kernels clear for each other start cleared (one memset per pass, not one per depth and
         // per tree and query: 102 of the wine glass's 354 fills per step)
@@ -490,8 +495,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         { Bracket b(h, RPT_K_RAYGEN, prof); kt->raygen(st, fr, cam, ps, n_paths); b.done(); }
         h->stats.samples += n_paths;
         uint32_t n_active = n_paths;
-        const uint32_t* queue = nullptr; // identity at depth 0
-        uint32_t* next = h->queue_a.p;
+        const uint32_t* const queue = nullptr; // the paths of a depth stand densely in its state arrays: the identity
+        uint32_t* const next = nullptr;
         uint64_t rec_off = 0; // the depth's first record column
         bool pool_ran_out = false;
         for (uint32_t depth = 0; depth <= p->max_bounces && n_active; depth++) {
@@ -547,8 +552,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           }
           rec_off += n_active;
           n_active = cnt[0];
-          queue = next;
-          next = (next == h->queue_a.p) ? h->queue_b.p : h->queue_a.p;
+          // the survivors' state is what rpt_shade wrote to the *_next arrays at their new positions
+          std::swap(ps.ray, ps.ray_next); std::swap(ps.draw, ps.draw_next); std::swap(ps.pid, ps.pid_next); std::swap(ps.col, ps.col_next);
         }
         if (pool_ran_out) {
           // more levels per path than the pool was sized for (another camera, a margin too thin): the pass starts over
@@ -632,7 +637,7 @@ int rptgpu_closest_hit(rptgpu_scene* h, uint64_t n, const double* origins, const
       ensure_workspace(h, piece, piece);
       rptdev::PathState ps{};
       ps.ray = h->ray.p; ps.hit = h->hit.p; ps.hit_obj = h->hit_obj.p; ps.draw = h->draw.p;
-      ps.nrec = h->nrec.p; ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
+      ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
       ps.shadow = h->shadow.p; ps.cap = h->ws_cap; ps.rec_cap = h->ws_rec_cols;
       const uint32_t trace_blocks = (uint32_t)std::max(1, h->num_cus * 4);
       std::vector<double> soa(6 * piece), hit(4 * piece);

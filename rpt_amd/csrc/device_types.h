@@ -155,17 +155,27 @@ struct Camera {
 constexpr int REC_FIELDS = 8;
 constexpr int SHADOW_FIELDS = 7; // wi[3], dist, contribution[3]
 
+// Round 6: the state of a depth is DENSE — index i is the path's position among the paths alive at this depth, not a
+// slot it keeps for life.  rpt_shade reads ray / hit / draw / pid / col at i and writes the survivors' state to the *_next
+// arrays at their position j in the next depth's queue (the host swaps the pairs), so every depth's kernels stream
+// contiguous state; until then the arrays were indexed by the path's slot through a queue of slots, and from the second
+// depth on every access was a scattered 8-byte gather (rpt_shade: 2.2 x the time per path of depth 0).
 struct PathState {
   double* ray;       // [6][cap]   ox oy oz dx dy dz
   double* hit;       // [4][cap]   t nx ny nz
   int32_t* hit_obj;  // [cap]      object index or -1
   uint32_t* draw;    // [cap]      Philox draw counter of the path's stream
-  uint8_t* nrec;     // [cap]      number of depth records the path produced (0 = still running)
+  uint32_t* pid;     // [cap]      which path: sample_local * npix + pixel_local (its Philox stream, its place in the frame)
+  uint32_t* col;     // [cap]      the column of the path's record one depth up (depth >= 1)
+  double* ray_next;  // the same four for the next depth, written by rpt_shade at the survivors' positions
+  uint32_t* draw_next;
+  uint32_t* pid_next;
+  uint32_t* col_next;
   double* rec;       // [REC_FIELDS][rec_cap]: the pass's depth records, one COLUMN per (path, depth) the path reached — the
                      // columns of depth d are [rec_off_d, rec_off_d + n_active_d) in the order of that depth's queue (round
                      // 6; until then [max_bounces + 1][REC_FIELDS][cap]: 1 088 B per path at 16 bounces whatever its length)
   uint32_t* rec_parent; // [rec_cap] the column of the same path's record one depth up (REC_NONE at depth 0)
-  uint32_t* last_col;   // [cap] the column of the path's deepest record so far
+  uint32_t* last_col;   // [cap] by path id: the column of the record the path ENDED with (written once, by its last rpt_shade)
   double* shadow;    // [num_lights][SHADOW_FIELDS][cap]
   uint64_t cap;      // slots allocated (stride of every per-path array above)
   uint64_t rec_cap;  // columns allocated (stride of rec's fields)
