@@ -132,6 +132,11 @@ struct rptgpu_scene {
   DevBuf<uint32_t> rec_parent, last_col;
   DevBuf<double> ray_next;             // dense path state of the NEXT depth (PathState: rpt_shade writes, the host swaps)
   DevBuf<uint32_t> draw_next, pid, pid_next, col, col_next;
+  // in-kernel-traversal scenes: the paths of a depth are re-ordered by ray key (kernels/wavefront.inc rpt_path_keys)
+  bool path_reorder = false;
+  uint32_t path_reorder_min = RPT_PATH_REORDER_MIN; // ... when a depth has at least this many (RPTGPU_PATH_REORDER_MIN: tests)
+  double scene_bounds[6] = {0, 0, 0, 1, 1, 1};
+  DevBuf<uint32_t> path_order;
   double rec_ratio = 0.0;              // record columns a path of this scene needs on average, as measured by the passes so
   uint32_t rec_ratio_bounces = 0xffffffffu; // far at this max_bounces (0 = not measured yet: the next pass measures)
   uint64_t ws_fail_paths = 0;          // the smallest pass (paths) whose workspace did not fit on this device so far; 0 = none

@@ -179,6 +179,12 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint64_t rec_cols) {
       h->sort_bufs = SortBufs{h->sort_kin.p, h->sort_kout.p, h->sort_vin.p, h->sort_tmp.p, bytes};
     }
   }
+  if (h->path_reorder) { // the per-depth re-order of the paths (in-kernel-traversal scenes): keys, positions, rocPRIM's scratch
+    h->sort_kin.alloc(cap); h->sort_kout.alloc(cap); h->sort_vin.alloc(cap); h->path_order.alloc(cap);
+    size_t bytes = rpt_strict::TABLE.sort_temp_bytes((uint32_t)cap);
+    h->sort_tmp.alloc(bytes);
+    h->sort_bufs = SortBufs{h->sort_kin.p, h->sort_kout.p, h->sort_vin.p, h->sort_tmp.p, bytes};
+  }
   h->ws_cap = cap;
   h->ws_rec_cols = rec_cols;
 }
@@ -219,6 +225,7 @@ void release_workspace(rptgpu_scene* h) {
   h->rec_parent.release(); h->last_col.release();
   h->shadow.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
   h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release(); h->tree_rays.release();
+  h->path_order.release();
   h->gen_defer.release(); h->gen_frame.release(); h->gen_threads = 0; // rpt_tree_generic's columns (ensure_generic makes them again)
   h->ws_cap = 0; h->ws_rec_cols = 0;
 }
@@ -394,7 +401,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       // (ray and next ray, hit, object, draw / path id / parent column twice each, last column, per light the shadow
       // state, queue entry and record time, the per-tree query's queue, row and sort words)
       const uint64_t per_slot = 2 * 6 * 8 + 4 * 8 + 4 + 6 * 4 + 4 + nl * rptdev::SHADOW_FIELDS * 8 + nl * (8 + 4) +
-                                (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0);
+                                (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0) + (h->path_reorder ? 16 + 16 : 0);
       const uint64_t per_rec = rptdev::REC_FIELDS * 8 + 4;
       const double full_ratio = (double)p->max_bounces + 1.0;
       if (h->rec_ratio_bounces != p->max_bounces) { h->rec_ratio = 0.0; h->rec_ratio_bounces = p->max_bounces; }
@@ -553,7 +560,15 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           rec_off += n_active;
           n_active = cnt[0];
           // the survivors' state is what rpt_shade wrote to the *_next arrays at their new positions
-          std::swap(ps.ray, ps.ray_next); std::swap(ps.draw, ps.draw_next); std::swap(ps.pid, ps.pid_next); std::swap(ps.col, ps.col_next);
+          if (!by_object && h->path_reorder && n_active >= h->path_reorder_min && depth < p->max_bounces) {
+            // ... gathered into the current arrays in the order of their rays' keys (behind the depth's shadow queries,
+            // which read the current arrays: same stream)
+            Bracket b(h, RPT_K_TREE_SORT, prof);
+            kt->path_reorder(st, ps, n_active, h->scene_bounds, &h->sort_bufs, h->path_order.p);
+            b.done();
+          } else {
+            std::swap(ps.ray, ps.ray_next); std::swap(ps.draw, ps.draw_next); std::swap(ps.pid, ps.pid_next); std::swap(ps.col, ps.col_next);
+          }
         }
         if (pool_ran_out) {
           // more levels per path than the pool was sized for (another camera, a margin too thin): the pass starts over

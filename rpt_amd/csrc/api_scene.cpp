@@ -259,6 +259,12 @@ int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOp
       h->has_deep = h->has_deep || deep;
     }
     h->gen_levels = fs.generic_levels; h->gen_frames = fs.generic_frames;
+    // scenes whose trees are all walked inside rpt_extend / rpt_shadow_rays get their paths re-ordered per depth
+    // (RPTGPU_PATH_REORDER: an A/B switch, environment only — scheduling, not results)
+    std::memcpy(h->scene_bounds, fs.scene_bounds, sizeof h->scene_bounds);
+    h->path_reorder = !h->has_deep && fs.scene_bounds_ok && !fs.trees.empty();
+    if (const char* e = std::getenv("RPTGPU_PATH_REORDER")) h->path_reorder = h->path_reorder && std::atoi(e) != 0;
+    if (const char* e = std::getenv("RPTGPU_PATH_REORDER_MIN")) h->path_reorder_min = (uint32_t)std::max(1, std::atoi(e));
     if (h->tree_kids) h->prefer_wavefront = true;
     h->all_flat = true;
     for (const rptdev::Tree& tr : fs.trees) h->all_flat = h->all_flat && tr.root_leaf != 0;

@@ -171,14 +171,14 @@ struct PathState {
   uint32_t* draw_next;
   uint32_t* pid_next;
   uint32_t* col_next;
-  double* rec;       // [REC_FIELDS][rec_cap]: the pass's depth records, one COLUMN per (path, depth) the path reached — the
+  double* rec;       // [rec_cap][REC_FIELDS]: the pass's depth records, one 64-byte COLUMN per (path, depth) the path reached — the
                      // columns of depth d are [rec_off_d, rec_off_d + n_active_d) in the order of that depth's queue (round
                      // 6; until then [max_bounces + 1][REC_FIELDS][cap]: 1 088 B per path at 16 bounces whatever its length)
   uint32_t* rec_parent; // [rec_cap] the column of the same path's record one depth up (REC_NONE at depth 0)
   uint32_t* last_col;   // [cap] by path id: the column of the record the path ENDED with (written once, by its last rpt_shade)
   double* shadow;    // [num_lights][SHADOW_FIELDS][cap]
   uint64_t cap;      // slots allocated (stride of every per-path array above)
-  uint64_t rec_cap;  // columns allocated (stride of rec's fields)
+  uint64_t rec_cap;  // columns allocated
 };
 constexpr uint32_t REC_NONE = 0xffffffffu;
 

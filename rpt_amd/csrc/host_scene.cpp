@@ -772,6 +772,20 @@ int flatten_scene(const RptScene& sc, FlatScene& fs, std::string& err, const Bui
     fs.lights.push_back(dl);
   }
   fill_object_boxes(fs, world, world_ok);
+  {
+    Box all = empty_box();
+    bool any = false;
+    for (size_t i = 0; i < world.size(); i++) {
+      bool good = world_ok[i] != 0;
+      for (int k = 0; k < 3 && good; k++) good = std::isfinite(world[i].lo[k]) && std::isfinite(world[i].hi[k]) && world[i].lo[k] <= world[i].hi[k];
+      if (good) { all = merge(all, world[i]); any = true; }
+    }
+    fs.scene_bounds_ok = any;
+    for (int k = 0; k < 3 && any; k++) {
+      fs.scene_bounds[k] = all.lo[k]; fs.scene_bounds[3 + k] = all.hi[k];
+      if (!(all.hi[k] > all.lo[k]) || !std::isfinite(all.hi[k] - all.lo[k])) fs.scene_bounds_ok = false;
+    }
+  }
   for (auto& g : fl.group_children) { // now place GROUP children and patch prim_base
     fs.trees[g.first].prim_base = (uint32_t)fs.insts.size();
     fs.insts.insert(fs.insts.end(), g.second.begin(), g.second.end());

@@ -65,6 +65,10 @@ struct FlatScene {
   double obj_grid[12] = {0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0}; // qlo[3], qscale[3], bounds[6]
   uint64_t obj_always = ~0ull;
   bool obj_filter_ok = false;
+  // union of the world-space boxes of the bounded top-level objects (planes have none): the grid of the path re-order's
+  // sort key (kernels/wavefront.inc rpt_path_keys); ok: there is at least one and it is finite and not flat
+  double scene_bounds[6] = {0, 0, 0, 1, 1, 1};
+  bool scene_bounds_ok = false;
   uint32_t trees_built_on_device = 0; // how many of the trees kd_build_device made (diagnostics)
   bool nested_mesh = false; // some KdTree<Box<dyn Bounded>> child is a Mesh, a MonomialSurface or another group:
                             // the scene needs the extended kernel builds

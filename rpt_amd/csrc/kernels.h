@@ -34,6 +34,10 @@ static inline uint32_t rpt_fold_ring_slots(uint32_t max_bounces) { return 3u * m
 #ifndef RPT_WS_FREE_PERCENT
 #define RPT_WS_FREE_PERCENT 85
 #endif
+// the paths of a depth are re-ordered by ray key in scenes without per-tree queues when there are at least this many
+#ifndef RPT_PATH_REORDER_MIN
+#define RPT_PATH_REORDER_MIN (1u << 20)
+#endif
 #define RPT_PATHS_BATCH_MAX 1024u
 #define RPT_PATHS_WAVES_PER_CU_MAX 32u
 
@@ -162,6 +166,8 @@ struct KernelTable {
   // -DRPT_PROF builds: the per-phase table of kernels/prof.inc since the last call ([0] wave cycles, [1] lane cycles,
   // [2] wave iterations, [3] lane iterations); false in regular builds
   bool (*read_prof)(unsigned long long out[4][24]);
+  // in-kernel-traversal scenes: the next depth's paths sorted by ray key into the current state arrays (kernels/wavefront.inc)
+  void (*path_reorder)(hipStream_t, const rptdev::PathState&, uint32_t n, const double* scene_bounds, const SortBufs* sort, uint32_t* order);
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)

@@ -406,6 +406,23 @@ def test_per_tree_queries_and_ray_sorting_do_not_change_the_image(name, sort, mo
     assert (img == load(name)["image"]).all()
 
 
+@pytest.mark.parametrize("reorder", ["0", "1"])
+@pytest.mark.parametrize("name", small_scenes.NAMES)
+def test_path_reorder_of_in_kernel_scenes_is_scheduling_only(name, reorder, monkeypatch):
+    """Round 6: scenes whose trees are walked inside rpt_extend / rpt_shadow_rays get the paths of a depth re-ordered by ray
+    key (dense path state makes the order free).  Forced on for every depth of every fixture (threshold 1 path) through the
+    wavefront pipeline, and off: the fixture's frame either way."""
+    monkeypatch.setenv("RPTGPU_PATH_REORDER", reorder)
+    monkeypatch.setenv("RPTGPU_PATH_REORDER_MIN", "1")
+    monkeypatch.setenv("RPTGPU_DEEP_DEPTH", "1000")  # nothing is "deep": every tree in-kernel
+    scene, cam, p = small_scenes.small(name)
+    g = GpuScene(scene, 0)
+    pw = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=_abi.RPT_FLAG_WAVEFRONT)
+    img = g.render_batch(cam, pw)
+    g.close()
+    assert (img == load(name)["image"]).all()
+
+
 @pytest.mark.parametrize("knobs", [{"RPTGPU_LEAF_BOXES": "0"}, {"RPTGPU_SORT_RAYS": "1"},
                                    {"RPTGPU_LEAF_BOXES": "0", "RPTGPU_SORT_RAYS": "1"},
                                    {"RPTGPU_NEST_TRACE": "0"},  # kd-trees of kd-trees through rpt_tree_generic instead of rpt_nest_trace
