@@ -486,6 +486,10 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         ps.ray_next = h->ray_next.p; ps.draw_next = h->draw_next.p; ps.pid_next = h->pid_next.p; ps.col_next = h->col_next.p;
         ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
         ps.shadow = h->shadow.p; ps.cap = h->ws_cap; ps.rec_cap = h->ws_rec_cols;
+        if (h->path_reorder && !(h->has_deep && (!(p->flags & RPT_FLAG_GENERAL_TRAVERSAL) || h->tree_kids))) {
+          ps.sort_keys = h->sort_kin.p; ps.sort_vals = h->sort_vin.p;
+          std::memcpy(ps.key_bounds, h->scene_bounds, sizeof ps.key_bounds);
+        }
         // the counter sets the kernels clear for each other start cleared (one memset per pass, not one per depth and
         // per tree and query: 102 of the wine glass's 354 fills per step)
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * (size_t)nctr * sizeof(uint32_t), st));

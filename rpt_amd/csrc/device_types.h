@@ -179,6 +179,9 @@ struct PathState {
   double* shadow;    // [num_lights][SHADOW_FIELDS][cap]
   uint64_t cap;      // slots allocated (stride of every per-path array above)
   uint64_t rec_cap;  // columns allocated
+  uint32_t* sort_keys; // path re-order (in-kernel-traversal scenes; nullptr = off): rpt_shade writes the survivor's ray key
+  uint32_t* sort_vals; // and its position here
+  double key_bounds[6]; // the key's grid: the bounds of the scene's bounded objects
 };
 constexpr uint32_t REC_NONE = 0xffffffffu;
 
