@@ -137,6 +137,7 @@ struct rptgpu_scene {
   uint32_t path_reorder_min = RPT_PATH_REORDER_MIN; // ... when a depth has at least this many (RPTGPU_PATH_REORDER_MIN: tests)
   double scene_bounds[6] = {0, 0, 0, 1, 1, 1};
   DevBuf<uint32_t> path_order;
+  DevBuf<double> next_rows;           // [cap][8]: the survivors' next state as rows (PathState::next_rows)
   double rec_ratio = 0.0;              // record columns a path of this scene needs on average, as measured by the passes so
   uint32_t rec_ratio_bounces = 0xffffffffu; // far at this max_bounces (0 = not measured yet: the next pass measures)
   uint64_t ws_fail_paths = 0;          // the smallest pass (paths) whose workspace did not fit on this device so far; 0 = none

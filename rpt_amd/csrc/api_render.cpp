@@ -141,12 +141,15 @@ void ensure_workspace(rptgpu_scene* h, uint64_t cap, uint64_t rec_cols) {
   rec_cols = std::max(rec_cols, h->ws_rec_cols);
   int nl = std::max(1, h->dscene.num_lights);
   h->ray.alloc(6 * cap);
-  h->ray_next.alloc(6 * cap);
   h->hit.alloc(4 * cap);
   h->hit_obj.alloc(cap);
-  h->draw.alloc(cap); h->draw_next.alloc(cap);
-  h->pid.alloc(cap); h->pid_next.alloc(cap);
-  h->col.alloc(cap); h->col_next.alloc(cap);
+  h->draw.alloc(cap); h->pid.alloc(cap); h->col.alloc(cap);
+  if (h->path_reorder) { // the survivors' next state as 64-byte rows (gathered in sorted order by rpt_path_permute)
+    h->next_rows.alloc(8 * cap);
+  } else {               // ... or as a second set of the arrays, swapped per depth
+    h->ray_next.alloc(6 * cap);
+    h->draw_next.alloc(cap); h->pid_next.alloc(cap); h->col_next.alloc(cap);
+  }
   h->last_col.alloc(cap);
   h->rec.release();
   h->rec.alloc((uint64_t)rptdev::REC_FIELDS * rec_cols);
@@ -225,7 +228,7 @@ void release_workspace(rptgpu_scene* h) {
   h->rec_parent.release(); h->last_col.release();
   h->shadow.release(); h->tq.release(); h->srt.release(); h->shadow_q.release();
   h->sort_kin.release(); h->sort_kout.release(); h->sort_vin.release(); h->sort_tmp.release(); h->tree_rays.release();
-  h->path_order.release();
+  h->path_order.release(); h->next_rows.release();
   h->gen_defer.release(); h->gen_frame.release(); h->gen_threads = 0; // rpt_tree_generic's columns (ensure_generic makes them again)
   h->ws_cap = 0; h->ws_rec_cols = 0;
 }
@@ -401,7 +404,7 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
       // (ray and next ray, hit, object, draw / path id / parent column twice each, last column, per light the shadow
       // state, queue entry and record time, the per-tree query's queue, row and sort words)
       const uint64_t per_slot = 2 * 6 * 8 + 4 * 8 + 4 + 6 * 4 + 4 + nl * rptdev::SHADOW_FIELDS * 8 + nl * (8 + 4) +
-                                (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0) + (h->path_reorder ? 16 + 16 : 0);
+                                (h->has_deep ? 12 + 64 + (h->sort_rays ? 12 + 16 : 0) : 0) + (h->path_reorder ? 16 + 16 + 4 : 0);
       const uint64_t per_rec = rptdev::REC_FIELDS * 8 + 4;
       const double full_ratio = (double)p->max_bounces + 1.0;
       if (h->rec_ratio_bounces != p->max_bounces) { h->rec_ratio = 0.0; h->rec_ratio_bounces = p->max_bounces; }
@@ -486,8 +489,8 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
         ps.ray_next = h->ray_next.p; ps.draw_next = h->draw_next.p; ps.pid_next = h->pid_next.p; ps.col_next = h->col_next.p;
         ps.rec = h->rec.p; ps.rec_parent = h->rec_parent.p; ps.last_col = h->last_col.p;
         ps.shadow = h->shadow.p; ps.cap = h->ws_cap; ps.rec_cap = h->ws_rec_cols;
-        if (h->path_reorder && !(h->has_deep && (!(p->flags & RPT_FLAG_GENERAL_TRAVERSAL) || h->tree_kids))) {
-          ps.sort_keys = h->sort_kin.p; ps.sort_vals = h->sort_vin.p;
+        if (h->path_reorder) { // (never with per-tree queues: api_scene.cpp)
+          ps.sort_keys = h->sort_kin.p; ps.sort_vals = h->sort_vin.p; ps.next_rows = h->next_rows.p;
           std::memcpy(ps.key_bounds, h->scene_bounds, sizeof ps.key_bounds);
         }
         // the counter sets the kernels clear for each other start cleared (one memset per pass, not one per depth and
@@ -564,12 +567,14 @@ int render_impl(rptgpu_scene* h, const RptCamera* camera, const RptRenderParams*
           rec_off += n_active;
           n_active = cnt[0];
           // the survivors' state is what rpt_shade wrote to the *_next arrays at their new positions
-          if (!by_object && h->path_reorder && n_active >= h->path_reorder_min && depth < p->max_bounces) {
-            // ... gathered into the current arrays in the order of their rays' keys (behind the depth's shadow queries,
-            // which read the current arrays: same stream)
-            Bracket b(h, RPT_K_TREE_SORT, prof);
-            kt->path_reorder(st, ps, n_active, h->scene_bounds, &h->sort_bufs, h->path_order.p);
-            b.done();
+          if (h->path_reorder) {
+            // ... as rows, gathered into the current arrays in the order of their rays' keys — or, a depth too small to be
+            // worth a sort, as they stand (behind the depth's shadow queries, which read the current arrays: same stream)
+            if (n_active && depth < p->max_bounces) {
+              Bracket b(h, RPT_K_TREE_SORT, prof);
+              kt->path_reorder(st, ps, n_active, n_active >= h->path_reorder_min, &h->sort_bufs, h->path_order.p);
+              b.done();
+            }
           } else {
             std::swap(ps.ray, ps.ray_next); std::swap(ps.draw, ps.draw_next); std::swap(ps.pid, ps.pid_next); std::swap(ps.col, ps.col_next);
           }

@@ -181,6 +181,8 @@ struct PathState {
   uint64_t rec_cap;  // columns allocated
   uint32_t* sort_keys; // path re-order (in-kernel-traversal scenes; nullptr = off): rpt_shade writes the survivor's ray key
   uint32_t* sort_vals; // and its position here
+  double* next_rows;   // ... and its next state as ONE 64-byte row [cap][8] (o, d, draw | pid, col | 0) instead of the *_next
+                       // arrays: rpt_path_permute gathers rows in sorted order — one sector per path, not nine
   double key_bounds[6]; // the key's grid: the bounds of the scene's bounded objects
 };
 constexpr uint32_t REC_NONE = 0xffffffffu;

@@ -167,7 +167,7 @@ struct KernelTable {
   // [2] wave iterations, [3] lane iterations); false in regular builds
   bool (*read_prof)(unsigned long long out[4][24]);
   // in-kernel-traversal scenes: the next depth's paths sorted by ray key into the current state arrays (kernels/wavefront.inc)
-  void (*path_reorder)(hipStream_t, const rptdev::PathState&, uint32_t n, const double* scene_bounds, const SortBufs* sort, uint32_t* order);
+  void (*path_reorder)(hipStream_t, const rptdev::PathState&, uint32_t n, bool sorted, const SortBufs* sort, uint32_t* order);
 };
 
 namespace rpt_strict { extern const KernelTable TABLE; } // -ffp-contract=off (parity mode)
