@@ -402,10 +402,14 @@ def roofline_object(wl, st, kernels, dominant, kern_n, bytes_k, pmc, pmc_note, p
             "kernels": kernels}
     k, src = None, None
     if pmc is not None:
-        raw = pmc["raw"].get(dominant)
+        # (RptStats brackets a depth's visibility queries as "rpt_shadow"; the profiler sees the kernel inside: rpt_shadow_rays)
+        pname = dominant if pmc["raw"].get(dominant) else {"rpt_shadow": "rpt_shadow_rays"}.get(dominant, dominant)
+        raw = pmc["raw"].get(pname)
         if raw:
             W, H = wl.W, wl.H
-            k = derive_counters(raw, float(W) * H * pmc_spp, pmc["dur_us"].get(dominant))
+            k = derive_counters(raw, float(W) * H * pmc_spp, pmc["dur_us"].get(pname))
+            if pname != dominant:
+                roof["counters_of"] = pname
             src = "live: rocprofv3 --pmc passes of one %d-spp step of this workload, run by this bench.py invocation" % pmc_spp
     if k is None:  # fall back to the committed summary of an earlier profile of the same workload
         import glob
