@@ -268,6 +268,7 @@ int rptgpu_scene_create_opts(const RptScene* scene, int device, const RptSceneOp
     if (h->tree_kids) h->prefer_wavefront = true;
     h->all_flat = true;
     for (const rptdev::Tree& tr : fs.trees) h->all_flat = h->all_flat && tr.root_leaf != 0;
+    if (h->all_flat) h->path_reorder = false; // every tree a single leaf: nothing in rpt_extend diverges by where a ray goes
     if (h->all_flat) { // does the scene fit a wave's share of LDS (160 KB per CU / 8 waves)?
       constexpr uint32_t WAVE_LDS = RPT_PATHS_WAVE_LDS - RPT_PATHS_WALKER_LDS; // the wave's share less the fold walker's state
       auto up16 = [](uint64_t v) { return (v + 15) & ~15ull; };
