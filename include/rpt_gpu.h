@@ -269,8 +269,10 @@ void rptgpu_scene_destroy(rptgpu_scene* h);
  * rptgpu_scene_create(scene, device, out) is rptgpu_scene_create_opts with them.  The environment variables named
  * beside the fields — the only interface until v5 — remain as OVERRIDES for experiments: read once, inside
  * rptgpu_scene_create[_opts], never afterwards (a handle's behaviour is fixed when it is made).  What is left in the
- * environment only: diagnostics (RPTGPU_PRINT_CREATE / _LAUNCH / _PHASES), the A/B switches RPTGPU_FLAT_TRIS_GLOBAL and
- * RPTGPU_NO_PLANE_TABLE, the tests' fault injection RPTGPU_FAIL_COMM, and the launcher's RPTGPU_LOCAL_RANKS /
+ * environment only: diagnostics (RPTGPU_PRINT_CREATE / _LAUNCH / _PHASES), the A/B switches RPTGPU_FLAT_TRIS_GLOBAL,
+ * RPTGPU_NO_PLANE_TABLE, RPTGPU_PATH_REORDER (the per-depth re-order of the paths in scenes whose trees are walked
+ * in-kernel) and RPTGPU_WS_FREE_FRACTION (percent of the free memory a pass may take: 85), the tests' hooks
+ * RPTGPU_FAIL_COMM, RPTGPU_PATH_REORDER_MIN and RPTGPU_REC_RATIO, and the launcher's RPTGPU_LOCAL_RANKS /
  * LOCAL_WORLD_SIZE (how many ranks share the host's cores). */
 typedef struct RptSceneOptions {
   uint32_t struct_size;           /* sizeof(RptSceneOptions) of the caller's header: lets the struct grow            */

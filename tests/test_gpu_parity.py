@@ -532,6 +532,29 @@ def test_small_workspace_chunks_give_the_same_image(built, monkeypatch):
     g2.close()
 
 
+@pytest.mark.parametrize("name", ["fractal_spheres", "dragon", "cornell", "glass"])
+def test_a_pass_whose_record_pool_runs_out_starts_over(name, monkeypatch, capfd):
+    """Round 6: depth records live in a pool of columns sized from a MEASURED average (columns per path).  A pass that needs
+    more — another camera, a thin margin — must start over with room for more, having left nothing behind: forced here by
+    claiming that a path needs a hundredth of a column (RPTGPU_REC_RATIO).  The fixture's frame, the sample count of ONE
+    rendering, and the library says (RPTGPU_PRINT_LAUNCH) that it did start over."""
+    monkeypatch.setenv("RPTGPU_REC_RATIO", "0.01")
+    monkeypatch.setenv("RPTGPU_PRINT_LAUNCH", "1")
+    scene, cam, p = small_scenes.small(name)
+    g = GpuScene(scene, 0)
+    g.reset_stats()
+    capfd.readouterr()
+    pw = make_params(p.width, p.height, p.max_bounces, p.iterations, p.exposure_value, p.seed, flags=_abi.RPT_FLAG_WAVEFRONT)
+    img = g.render_batch(cam, pw)
+    err = capfd.readouterr().err
+    st = g.stats()
+    g.close()
+    assert (img == load(name)["image"]).all()
+    assert st.samples == p.width * p.height * p.iterations
+    if p.max_bounces > 0:
+        assert "started over" in err, err[-400:]
+
+
 def test_persistent_work_item_size_and_launch_split_do_not_change_the_image(built, monkeypatch):
     # samples per work item and the split of a batch into launches (per-sample radiance buffer cap)
     # are scheduling details: a pixel's samples are always summed in sample order
